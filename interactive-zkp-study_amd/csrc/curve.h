@@ -1,0 +1,161 @@
+// curve.h -- BN254 G1 (over F_p) and G2 (twist over F_p^2) group arithmetic, a = 0 curves,
+// in extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2), which give the
+// cheapest mixed addition (8M+2S) for Pippenger bucket accumulation.  Infinity: ZZ == 0.
+//
+// Replaces (as arithmetic) py_ecc.bn128.add/double/multiply/neg used through the aliases at
+// zkp/groth16/proving.py:12-15 and the wrappers zkp/plonk/field.py:72-115.  Results are
+// converted back to canonical affine, so they equal the reference's affine values exactly.
+#pragma once
+#include "field.h"
+
+namespace zk {
+
+template <class F> struct Affine {
+    F x, y;  // Montgomery form; infinity encoded as x = y = 0 (not on either curve)
+    ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    static ZK_HD Affine inf() { return Affine{F::zero(), F::zero()}; }
+};
+
+template <class F> struct Xyzz {
+    F x, y, zz, zzz;
+    ZK_HD bool is_inf() const { return zz.is_zero(); }
+    static ZK_HD Xyzz inf() { return Xyzz{F::zero(), F::zero(), F::zero(), F::zero()}; }
+    static ZK_HD Xyzz from_affine(const Affine<F> &p) {
+        if (p.is_inf()) return inf();
+        return Xyzz{p.x, p.y, F::one(), F::one()};
+    }
+};
+
+template <class F> ZK_HD Affine<F> affine_neg(const Affine<F> &p) { return Affine<F>{p.x, fe_neg(p.y)}; }
+template <class F> ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F> &p) { return Xyzz<F>{p.x, fe_neg(p.y), p.zz, p.zzz}; }
+
+// 2*P for affine P (mdbl-2008-s-1).
+template <class F> ZK_HD Xyzz<F> xyzz_dbl_affine(const Affine<F> &p) {
+    if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
+    F u = fe_dbl(p.y);
+    F v = fe_sqr(u);
+    F w = fe_mul(u, v);
+    F s = fe_mul(p.x, v);
+    F x2 = fe_sqr(p.x);
+    F m = fe_add(fe_dbl(x2), x2);
+    Xyzz<F> r;
+    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
+    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, p.y));
+    r.zz = v;
+    r.zzz = w;
+    return r;
+}
+
+// 2*P (dbl-2008-s-1).
+template <class F> ZK_HD Xyzz<F> xyzz_dbl(const Xyzz<F> &p) {
+    if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
+    F u = fe_dbl(p.y);
+    F v = fe_sqr(u);
+    F w = fe_mul(u, v);
+    F s = fe_mul(p.x, v);
+    F x2 = fe_sqr(p.x);
+    F m = fe_add(fe_dbl(x2), x2);
+    Xyzz<F> r;
+    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
+    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, p.y));
+    r.zz = fe_mul(v, p.zz);
+    r.zzz = fe_mul(w, p.zzz);
+    return r;
+}
+
+// acc += q, q affine (madd-2008-s), all exceptional cases handled.
+template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) {
+    if (q.is_inf()) return;
+    if (acc.is_inf()) {
+        acc = Xyzz<F>{q.x, q.y, F::one(), F::one()};
+        return;
+    }
+    F u2 = fe_mul(q.x, acc.zz);
+    F s2 = fe_mul(q.y, acc.zzz);
+    F p = fe_sub(u2, acc.x);
+    F r = fe_sub(s2, acc.y);
+    if (p.is_zero()) {
+        if (r.is_zero())
+            acc = xyzz_dbl_affine(q);
+        else
+            acc = Xyzz<F>::inf();
+        return;
+    }
+    F pp = fe_sqr(p);
+    F ppp = fe_mul(p, pp);
+    F qq = fe_mul(acc.x, pp);
+    F x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(qq));
+    F y3 = fe_sub(fe_mul(r, fe_sub(qq, x3)), fe_mul(acc.y, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe_mul(acc.zz, pp);
+    acc.zzz = fe_mul(acc.zzz, ppp);
+}
+
+// acc += q (add-2008-s), all exceptional cases handled.
+template <class F> ZK_HD void xyzz_add(Xyzz<F> &acc, const Xyzz<F> &q) {
+    if (q.is_inf()) return;
+    if (acc.is_inf()) {
+        acc = q;
+        return;
+    }
+    F u1 = fe_mul(acc.x, q.zz);
+    F u2 = fe_mul(q.x, acc.zz);
+    F s1 = fe_mul(acc.y, q.zzz);
+    F s2 = fe_mul(q.y, acc.zzz);
+    F p = fe_sub(u2, u1);
+    F r = fe_sub(s2, s1);
+    if (p.is_zero()) {
+        if (r.is_zero())
+            acc = xyzz_dbl(acc);
+        else
+            acc = Xyzz<F>::inf();
+        return;
+    }
+    F pp = fe_sqr(p);
+    F ppp = fe_mul(p, pp);
+    F qq = fe_mul(u1, pp);
+    F x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(qq));
+    F y3 = fe_sub(fe_mul(r, fe_sub(qq, x3)), fe_mul(s1, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);
+    acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), ppp);
+}
+
+// Affine x = X/ZZ, y = Y/ZZZ with one inversion: since ZZ^3 = ZZZ^2, 1/ZZ = (ZZ/ZZZ)^2.
+template <class F> ZK_HD Affine<F> xyzz_to_affine(const Xyzz<F> &p) {
+    if (p.is_inf()) return Affine<F>::inf();
+    F izzz = fe_inv(p.zzz);
+    F izz = fe_sqr(fe_mul(p.zz, izzz));
+    return Affine<F>{fe_mul(p.x, izz), fe_mul(p.y, izzz)};
+}
+
+// k*P by MSB-first double-and-add over a 256-bit little-endian limb scalar.
+template <class F> ZK_HD Xyzz<F> xyzz_scalar_mul(const Affine<F> &p, const uint32_t k[8]) {
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (int i = 7; i >= 0; i--) {
+        for (int b = 31; b >= 0; b--) {
+            acc = xyzz_dbl(acc);
+            if ((k[i] >> b) & 1) xyzz_add_affine(acc, p);
+        }
+    }
+    return acc;
+}
+
+// k*P for a small non-negative k (bucket-segment bases in the reduction).
+template <class F> ZK_HD Xyzz<F> xyzz_small_mul(const Xyzz<F> &p, uint32_t k) {
+    Xyzz<F> acc = Xyzz<F>::inf();
+    for (int b = 31; b >= 0; b--) {
+        acc = xyzz_dbl(acc);
+        if ((k >> b) & 1) xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+typedef Affine<Fp> G1Affine;
+typedef Xyzz<Fp> G1Xyzz;
+typedef Affine<Fp2> G2Affine;
+typedef Xyzz<Fp2> G2Xyzz;
+
+}  // namespace zk
