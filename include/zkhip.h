@@ -1,0 +1,129 @@
+/*
+ * zkhip.h -- C ABI of libzkhip.so: MI355X (gfx950) MSM / NTT prover backend for BN254.
+ *
+ * The reference (tokamak-network/interactive-zkp-study) is pure Python and has NO FFI or
+ * plugin interface for this path.  Its de-facto seam is a set
+ * of Python call sites; each entry point below names the reference interface it replaces.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - Field elements: 4 x uint64 little-endian limbs, canonical residues (< modulus).
+ *     This is int(FR(x)) / int(FQ(x)) of the reference, split into limbs.
+ *   - G1 affine point: 8 limbs  x || y                      (py_ecc tuple (FQ, FQ)).
+ *   - G2 affine point: 16 limbs x.c0 || x.c1 || y.c0 || y.c1 (py_ecc (FQ2, FQ2), coeffs[0], coeffs[1]).
+ *   - Point at infinity (Python None): all coordinate limbs zero ((0,0) is on neither curve).
+ *     Outputs additionally report it through *out_is_inf.
+ *   - Scalars must be canonical (< r).  The reference reduces mod r before multiplying
+ *     (zkp/plonk/field.py:86-88); the Python layer does the same before calling in.
+ *   - Ownership: the caller allocates and frees every buffer it passes.  The library owns only
+ *     the handles it returns (zk_*_create / zk_*_destroy).
+ *   - Errors: 0 = ZK_OK, negative = failure; zk_last_error() returns a thread-local message.
+ *   - There is no CPU fallback: without a usable HIP device every compute entry point fails
+ *     with ZK_ERR_NO_DEVICE.
+ *   - "_dev" entry points take DEVICE pointers (hipMalloc'd, or torch tensor .data_ptr()) and a
+ *     hipStream_t passed as void* (NULL = default stream); they enqueue work and, where noted,
+ *     synchronise that stream only to read back the O(1)-size result.
+ */
+#ifndef ZKHIP_H
+#define ZKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_ERR_INVALID (-1)   /* bad argument (null pointer, size, non-canonical input)        */
+#define ZK_ERR_HIP (-2)       /* a HIP runtime call failed; see zk_last_error()                  */
+#define ZK_ERR_NO_DEVICE (-3) /* no HIP device visible                                           */
+#define ZK_ERR_NOMEM (-4)     /* host or device allocation failed                                */
+
+#define ZK_GROUP_G1 1
+#define ZK_GROUP_G2 2
+
+const char *zk_last_error(void);
+int zk_version(void);                 /* ABI version, currently 1 */
+int zk_device_count(int *count);      /* number of HIP devices (0 is not an error) */
+int zk_set_device(int device);        /* hipSetDevice for the calling thread */
+
+/* ------------------------------------------------------------------------------------------
+ * MSM  sum_i scalars[i] * points[i]
+ * Replaces the reference's scalar-mul-and-add loops:
+ *   zkp/plonk/kzg.py:59-65 (commit), zkp/groth16/proving.py:27-31,39-43,56-60,66-73 (proof_a/b/c).
+ * Terms with a zero scalar or an infinity point contribute nothing (kzg.py:62-63).
+ * n == 0 gives infinity (commit of the zero polynomial is None: tests/plonk/test_crypto.py:132-136).
+ */
+int zk_msm_g1(const uint64_t *scalars /* n*4 */, const uint64_t *points /* n*8 */, size_t n,
+              uint64_t out_xy[8], int *out_is_inf);
+int zk_msm_g2(const uint64_t *scalars /* n*4 */, const uint64_t *points /* n*16 */, size_t n,
+              uint64_t out_xy[16], int *out_is_inf);
+
+/* Device-resident MSM.  A plan owns the workspace for MSMs of up to max_n points. */
+typedef struct zk_msm_plan zk_msm_plan;
+int zk_msm_plan_create(int group /* ZK_GROUP_G1|G2 */, size_t max_n, zk_msm_plan **plan);
+int zk_msm_plan_destroy(zk_msm_plan *plan);
+/* Window width the plan will use for n points (Pippenger c); informational. */
+int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n);
+/* Runs the whole MSM on `stream`; returns after the (tiny) window sums have been read back
+ * and folded, i.e. the result is final.  out_xy: 8 (G1) or 16 (G2) limbs on the HOST. */
+int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n,
+               uint64_t *out_xy, int *out_is_inf, void *stream);
+/* Same, but returns the result as a projective partial sum (HOST, 16 limbs per coordinate set:
+ * G1 = 4*4 limbs X,Y,ZZ,ZZZ Montgomery form; G2 = 4*8 limbs) for multi-GPU folding. */
+int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n,
+                       uint64_t *out_xyzz, void *stream);
+/* Folds `count` partial sums (as written by zk_msm_dev_partial, e.g. all-gathered over RCCL
+ * from the ranks that each hold a chunk of the points) in rank order into one affine point.
+ * Host-side, O(count) group additions; this is the "all-reduce of partial sums" epilogue
+ * (RCCL has no elliptic-curve reduction operator). */
+int zk_msm_fold_partials(int group, const uint64_t *partials, size_t count, uint64_t *out_xy, int *out_is_inf);
+/* Limbs per partial for a group (16 for G1, 32 for G2). */
+int zk_msm_partial_limbs(int group);
+
+/* ------------------------------------------------------------------------------------------
+ * NTT over F_r, natural order in and out, omega_n = 5^((r-1)/n)   (zkp/plonk/field.py:178-180)
+ * Replaces fft / ifft (zkp/plonk/polynomial.py:292-341, 344-378) and, with a coset shift k,
+ * coset_fft / coset_ifft (zkp/plonk/utils.py:145-205; the reference's default k is 5):
+ *   inverse == 0: data[i] <- sum_j (k^j data[j]) * omega^(i j)
+ *   inverse != 0: data[j] <- k^-j * n^-1 * sum_i data[i] * omega^(-i j)
+ * coset_shift == NULL means k = 1 (plain fft / ifft).  1 <= 2^log_n <= 2^28 (field.py:169-172).
+ */
+int zk_ntt_fr(uint64_t *data /* n*4, in place, HOST */, unsigned log_n, int inverse,
+              const uint64_t coset_shift[4] /* nullable */);
+
+typedef struct zk_ntt_plan zk_ntt_plan;
+int zk_ntt_plan_create(unsigned log_n, zk_ntt_plan **plan);
+int zk_ntt_plan_destroy(zk_ntt_plan *plan);
+/* In-place transform of a DEVICE buffer of n*4 limbs.  Enqueues on `stream` and returns without
+ * synchronising.  coset_shift is a HOST pointer (nullable). */
+int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t coset_shift[4], void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * F_r vector helpers on DEVICE buffers (the pointwise part of the at-scale quotient,
+ * replacing the O(n^2) zkp/groth16/poly_utils.py:17-45,116-125 path):
+ *   out[i] = (a[i]*b[i] - c[i]) * zinv        (zinv: HOST pointer to one element)
+ */
+int zk_fr_quotient_dev(void *d_out, const void *d_a, const void *d_b, const void *d_c,
+                       const uint64_t zinv[4], size_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fixed-base batch scalar multiplication out[i] = scalars[i] * base  (HOST buffers).
+ * Replaces the setup-side loops zkp/groth16/setup.py:18-23,56-60,65-69 and
+ * zkp/plonk/srs.py:77-85 (one bn128.multiply(G, k_i) per element).
+ */
+int zk_fixed_base_g1(const uint64_t base_xy[8], const uint64_t *scalars, size_t n, uint64_t *out_points /* n*8 */);
+int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t n, uint64_t *out_points /* n*16 */);
+
+/* ------------------------------------------------------------------------------------------
+ * Single group operations on the device (HOST buffers; batch of n independent operations).
+ * Replace the seam zkp/plonk/field.py:72-115 (ec_mul / ec_add / ec_neg) where the Python layer
+ * needs individual points (proof_c's prf_A*s, verifier-side glue).  op: 0 = P+Q, 1 = k*P.
+ */
+int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scalar, size_t n, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKHIP_H */

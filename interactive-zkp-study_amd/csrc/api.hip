@@ -1,0 +1,289 @@
+// api.hip -- the extern "C" surface of libzkhip.so (declared in include/zkhip.h).
+#include <string.h>
+#include <memory>
+#include <vector>
+#include "common.h"
+#include "curve.h"
+#include "host_field.h"
+#include "msm.h"
+#include "ntt.h"
+
+namespace zk {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_last_error("no HIP device available (libzkhip has no CPU fallback)");
+        return ZK_ERR_NO_DEVICE;
+    }
+    return ZK_OK;
+}
+
+static bool scalars_canonical(const uint64_t *s, size_t n) {
+    const HFr m = HFr::modulus();
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t *v = s + 4 * i;
+        bool lt = false;
+        for (int k = 3; k >= 0; k--) {
+            if (v[k] < m.l[k]) { lt = true; break; }
+            if (v[k] > m.l[k]) break;
+        }
+        if (!lt) return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ batch group-op kernels
+template <class F> __device__ __forceinline__ Affine<F> load_affine_canonical(const uint32_t *p);
+template <> __device__ __forceinline__ Affine<Fp> load_affine_canonical<Fp>(const uint32_t *p) {
+    Affine<Fp> a;
+    for (int i = 0; i < 8; i++) { a.x.l[i] = p[i]; a.y.l[i] = p[8 + i]; }
+    const bool inf = a.is_inf();
+    a.x = fe_to_mont(a.x); a.y = fe_to_mont(a.y);
+    return inf ? Affine<Fp>::inf() : a;
+}
+template <> __device__ __forceinline__ Affine<Fp2> load_affine_canonical<Fp2>(const uint32_t *p) {
+    Affine<Fp2> a;
+    for (int i = 0; i < 8; i++) { a.x.c0.l[i] = p[i]; a.x.c1.l[i] = p[8 + i]; a.y.c0.l[i] = p[16 + i]; a.y.c1.l[i] = p[24 + i]; }
+    const bool inf = a.is_inf();
+    a.x = fe_to_mont(a.x); a.y = fe_to_mont(a.y);
+    return inf ? Affine<Fp2>::inf() : a;
+}
+__device__ __forceinline__ void store_fe_canonical(uint32_t *o, const Fp &a) {
+    Fp c = fe_from_mont(a);
+    for (int i = 0; i < 8; i++) o[i] = c.l[i];
+}
+__device__ __forceinline__ void store_affine_canonical(uint32_t *o, const Affine<Fp> &a) {
+    store_fe_canonical(o, a.x); store_fe_canonical(o + 8, a.y);
+}
+__device__ __forceinline__ void store_affine_canonical(uint32_t *o, const Affine<Fp2> &a) {
+    store_fe_canonical(o, a.x.c0); store_fe_canonical(o + 8, a.x.c1);
+    store_fe_canonical(o + 16, a.y.c0); store_fe_canonical(o + 24, a.y.c1);
+}
+
+// op 0: out[i] = p[i] + q[i];  op 1: out[i] = k[i] * p[i];  op 2: out[i] = k[i] * p[0] (fixed base)
+template <class F>
+__global__ __launch_bounds__(64) void group_op_kernel(int op, const uint32_t *p, const uint32_t *q, uint32_t *out, uint32_t n) {
+    constexpr int PW = sizeof(Affine<F>) / 4;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Xyzz<F> r;
+    if (op == 0) {
+        r = Xyzz<F>::from_affine(load_affine_canonical<F>(p + (size_t)i * PW));
+        xyzz_add_affine(r, load_affine_canonical<F>(q + (size_t)i * PW));
+    } else {
+        const Affine<F> base = load_affine_canonical<F>(p + (op == 2 ? 0 : (size_t)i * PW));
+        uint32_t k[8];
+        for (int j = 0; j < 8; j++) k[j] = q[(size_t)i * 8 + j];
+        r = xyzz_scalar_mul(base, k);
+    }
+    store_affine_canonical(out + (size_t)i * PW, xyzz_to_affine(r));
+}
+
+template <class F> static int group_op_host(int op, const uint64_t *p, const uint64_t *q, size_t n, uint64_t *out) {
+    constexpr size_t PB = sizeof(Affine<F>);
+    if (n == 0) return ZK_OK;
+    const size_t p_bytes = (op == 2 ? 1 : n) * PB, q_bytes = n * (op == 0 ? PB : 32);
+    DevBuf dp(p_bytes), dq(q_bytes), dout(n * PB);
+    ZK_HIP(hipMemcpy(dp.p, p, p_bytes, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(dq.p, q, q_bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((group_op_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, dp.as<uint32_t>(), dq.as<uint32_t>(),
+                       dout.as<uint32_t>(), (uint32_t)n);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpy(out, dout.p, n * PB, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+
+template <class F> static int msm_host(int group, const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t *out_xy, int *out_is_inf) {
+    constexpr size_t PB = sizeof(Affine<F>);
+    if (n == 0) {
+        memset(out_xy, 0, PB);
+        if (out_is_inf) *out_is_inf = 1;
+        return ZK_OK;
+    }
+    if (!scalars_canonical(scalars, n)) return invalid("zk_msm: scalar not canonical (>= r)");
+    std::unique_ptr<MsmPlanBase> plan(msm_plan_new(group, n));
+    DevBuf ds(n * 32), dp(n * PB);
+    ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(dp.p, points, n * PB, hipMemcpyHostToDevice));
+    return plan->run_affine(ds.p, dp.p, n, out_xy, out_is_inf, 0);
+}
+
+template <class F> static int fold_partials(const uint64_t *partials, size_t count, uint64_t *out_xy, int *out_is_inf) {
+    typedef typename HostOf<F>::type HF;
+    Xyzz<HF> acc = Xyzz<HF>::inf();
+    for (size_t i = 0; i < count; i++) {
+        Xyzz<HF> p;
+        memcpy(&p, partials + i * (sizeof(Xyzz<HF>) / 8), sizeof(p));
+        xyzz_add(acc, p);
+    }
+    write_affine<F>(acc, out_xy, out_is_inf);
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+struct zk_msm_plan {
+    std::unique_ptr<MsmPlanBase> impl;
+};
+struct zk_ntt_plan {
+    std::unique_ptr<NttPlan> impl;
+};
+
+extern "C" {
+
+const char *zk_last_error(void) { return g_last_error.c_str(); }
+int zk_version(void) { return 1; }
+
+int zk_device_count(int *count) {
+    if (!count) return invalid("zk_device_count: null pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return ZK_OK;
+}
+int zk_set_device(int device) {
+    return guarded([&] {
+        int rc = require_device();
+        if (rc) return rc;
+        ZK_HIP(hipSetDevice(device));
+        return ZK_OK;
+    });
+}
+
+int zk_msm_g1(const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t out_xy[8], int *out_is_inf) {
+    return guarded([&] {
+        if (!out_xy || (n && (!scalars || !points))) return invalid("zk_msm_g1: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        return msm_host<Fp>(ZK_GROUP_G1, scalars, points, n, out_xy, out_is_inf);
+    });
+}
+int zk_msm_g2(const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t out_xy[16], int *out_is_inf) {
+    return guarded([&] {
+        if (!out_xy || (n && (!scalars || !points))) return invalid("zk_msm_g2: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        return msm_host<Fp2>(ZK_GROUP_G2, scalars, points, n, out_xy, out_is_inf);
+    });
+}
+
+int zk_msm_plan_create(int group, size_t max_n, zk_msm_plan **plan) {
+    return guarded([&] {
+        if (!plan || (group != ZK_GROUP_G1 && group != ZK_GROUP_G2) || max_n == 0 || max_n > ((size_t)1 << 30))
+            return invalid("zk_msm_plan_create: bad argument");
+        int rc = require_device();
+        if (rc) return rc;
+        zk_msm_plan *p = new zk_msm_plan;
+        p->impl.reset(msm_plan_new(group, max_n));
+        *plan = p;
+        return ZK_OK;
+    });
+}
+int zk_msm_plan_destroy(zk_msm_plan *plan) {
+    delete plan;
+    return ZK_OK;
+}
+int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n) { return plan ? plan->impl->window_bits(n) : ZK_ERR_INVALID; }
+int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, void *stream) {
+    return guarded([&] {
+        if (!plan || !out_xy || (n && (!d_scalars || !d_points))) return invalid("zk_msm_dev: null pointer");
+        return plan->impl->run_affine(d_scalars, d_points, n, out_xy, out_is_inf, (hipStream_t)stream);
+    });
+}
+int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, void *stream) {
+    return guarded([&] {
+        if (!plan || !out_xyzz || (n && (!d_scalars || !d_points))) return invalid("zk_msm_dev_partial: null pointer");
+        return plan->impl->run_partial(d_scalars, d_points, n, out_xyzz, (hipStream_t)stream);
+    });
+}
+int zk_msm_partial_limbs(int group) { return group == ZK_GROUP_G1 ? 16 : group == ZK_GROUP_G2 ? 32 : ZK_ERR_INVALID; }
+int zk_msm_fold_partials(int group, const uint64_t *partials, size_t count, uint64_t *out_xy, int *out_is_inf) {
+    return guarded([&] {
+        if (!out_xy || (count && !partials)) return invalid("zk_msm_fold_partials: null pointer");
+        if (group == ZK_GROUP_G1) return fold_partials<Fp>(partials, count, out_xy, out_is_inf);
+        if (group == ZK_GROUP_G2) return fold_partials<Fp2>(partials, count, out_xy, out_is_inf);
+        return invalid("zk_msm_fold_partials: bad group");
+    });
+}
+
+int zk_fixed_base_g1(const uint64_t base_xy[8], const uint64_t *scalars, size_t n, uint64_t *out_points) {
+    return guarded([&] {
+        if (!base_xy || (n && (!scalars || !out_points))) return invalid("zk_fixed_base_g1: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        return group_op_host<Fp>(2, base_xy, scalars, n, out_points);
+    });
+}
+int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t n, uint64_t *out_points) {
+    return guarded([&] {
+        if (!base_xy || (n && (!scalars || !out_points))) return invalid("zk_fixed_base_g2: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        return group_op_host<Fp2>(2, base_xy, scalars, n, out_points);
+    });
+}
+int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scalar, size_t n, uint64_t *out) {
+    return guarded([&] {
+        if ((n && (!p || !q_or_scalar || !out)) || (op != 0 && op != 1)) return invalid("zk_group_op: bad argument");
+        int rc = require_device();
+        if (rc) return rc;
+        if (group == ZK_GROUP_G1) return group_op_host<Fp>(op, p, q_or_scalar, n, out);
+        if (group == ZK_GROUP_G2) return group_op_host<Fp2>(op, p, q_or_scalar, n, out);
+        return invalid("zk_group_op: bad group");
+    });
+}
+
+int zk_ntt_plan_create(unsigned log_n, zk_ntt_plan **plan) {
+    return guarded([&] {
+        if (!plan || log_n > 28) return invalid("zk_ntt_plan_create: log_n must be <= 28");
+        int rc = require_device();
+        if (rc) return rc;
+        zk_ntt_plan *p = new zk_ntt_plan;
+        p->impl.reset(new NttPlan(log_n));
+        *plan = p;
+        return ZK_OK;
+    });
+}
+int zk_ntt_plan_destroy(zk_ntt_plan *plan) {
+    delete plan;
+    return ZK_OK;
+}
+int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t coset_shift[4], void *stream) {
+    return guarded([&] {
+        if (!plan || !d_data) return invalid("zk_ntt_dev: null pointer");
+        plan->impl->run(d_data, inverse != 0, coset_shift, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t coset_shift[4]) {
+    return guarded([&] {
+        if (!data || log_n > 28) return invalid("zk_ntt_fr: bad argument");
+        int rc = require_device();
+        if (rc) return rc;
+        const size_t n = (size_t)1 << log_n;
+        if (!scalars_canonical(data, n)) return invalid("zk_ntt_fr: element not canonical (>= r)");
+        NttPlan plan(log_n);
+        DevBuf d(n * 32);
+        ZK_HIP(hipMemcpy(d.p, data, n * 32, hipMemcpyHostToDevice));
+        plan.run(d.p, inverse != 0, coset_shift, 0);
+        ZK_HIP(hipDeviceSynchronize());
+        ZK_HIP(hipMemcpy(data, d.p, n * 32, hipMemcpyDeviceToHost));
+        return ZK_OK;
+    });
+}
+int zk_fr_quotient_dev(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, void *stream) {
+    return guarded([&] {
+        if (!d_out || !d_a || !d_b || !d_c || !zinv) return invalid("zk_fr_quotient_dev: null pointer");
+        fr_quotient(d_out, d_a, d_b, d_c, zinv, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+
+}  // extern "C"

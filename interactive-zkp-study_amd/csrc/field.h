@@ -55,7 +55,7 @@ template <> struct FieldConst<FrTag> {
 };
 
 // A field element; value semantics, limbs in l[0] (least significant) .. l[7].
-template <class Tag> struct Fe {
+template <class Tag> struct alignas(16) Fe {
     uint32_t l[8];
     typedef FieldConst<Tag> C;
 

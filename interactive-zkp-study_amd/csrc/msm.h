@@ -1,0 +1,50 @@
+// msm.h -- internal interface between the C-ABI (api.hip) and the MSM pipeline (msm.hip).
+#pragma once
+#include <stdexcept>
+#include "common.h"
+#include "curve.h"
+#include "host_field.h"
+
+namespace zk {
+
+struct MsmPlanBase {
+    int group = 0;
+    virtual ~MsmPlanBase() {}
+    virtual int window_bits(size_t n) const = 0;
+    virtual int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) = 0;
+    virtual int run_partial(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, hipStream_t st) = 0;
+};
+MsmPlanBase *msm_plan_new(int group, size_t max_n);
+
+// Host XYZZ (Montgomery) -> canonical affine limbs; infinity -> zeros + flag.
+inline void write_fe_canonical(const HFp &a, uint64_t *out) {
+    HFp c = fe_from_mont(a);
+    memcpy(out, c.l, 32);
+}
+inline void write_fe_canonical(const HFp2 &a, uint64_t *out) {
+    write_fe_canonical(a.c0, out);
+    write_fe_canonical(a.c1, out + 4);
+}
+template <class F> inline void write_affine(const Xyzz<typename HostOf<F>::type> &p, uint64_t *out_xy, int *out_is_inf) {
+    constexpr int L = sizeof(F) / 8;  // limbs per coordinate
+    if (p.is_inf()) {
+        memset(out_xy, 0, 2 * L * 8);
+        if (out_is_inf) *out_is_inf = 1;
+        return;
+    }
+    auto a = xyzz_to_affine(p);
+    write_fe_canonical(a.x, out_xy);
+    write_fe_canonical(a.y, out_xy + L);
+    if (out_is_inf) *out_is_inf = 0;
+}
+
+inline HFp read_fe_canonical_fp(const uint64_t *in) {
+    HFp a;
+    memcpy(a.l, in, 32);
+    return fe_to_mont(a);
+}
+template <class HF> inline HF read_fe_canonical(const uint64_t *in);
+template <> inline HFp read_fe_canonical<HFp>(const uint64_t *in) { return read_fe_canonical_fp(in); }
+template <> inline HFp2 read_fe_canonical<HFp2>(const uint64_t *in) { return HFp2{read_fe_canonical_fp(in), read_fe_canonical_fp(in + 4)}; }
+
+}  // namespace zk

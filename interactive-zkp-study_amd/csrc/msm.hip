@@ -1,0 +1,411 @@
+// msm.hip -- Pippenger multi-scalar multiplication on BN254 G1 / G2 for gfx950.
+//
+// Replaces the reference's scalar-mul-and-add loops (zkp/plonk/kzg.py:59-65,
+// zkp/groth16/proving.py:23-75).  Pipeline (all kernels on one stream, no host sync until the
+// final 32 KiB read-back):
+//
+//   prepare      one thread per point: canonical affine -> Montgomery affine (workspace, resident
+//                for all windows), scalar -> W signed c-bit digits (int16, window-major).
+//   accumulate   one workgroup owns NT consecutive buckets of one window.  It streams that
+//                window's digit row (L2-resident), stages the matching (point index, sign)
+//                entries in LDS bucket lists (LDS-atomic counting sort), then each thread adds
+//                its bucket's points in XYZZ mixed coordinates (8M+2S per point).
+//   reduce       sum_j (j+1)*B_j per window without any serial running sum: log2(nb) "pair"
+//                levels (L[l+1][j] = L[l][2j] + L[l][2j+1]) plus plain sums O_l of the odd
+//                entries of every level (serial-4 per lane + wavefront __shfl tree), since
+//                sum_j j*B_j = sum_l 2^l * O_l.
+//   fold (host)  the W*(c) window/level sums (32 KiB) are read back and combined by one
+//                254-doubling Horner pass on the host (a single GPU thread would be latency-bound).
+#include <vector>
+#include "common.h"
+#include "curve.h"
+#include "host_field.h"
+#include "msm.h"
+
+namespace zk {
+
+// ------------------------------------------------------------------------------ device helpers
+template <class T> __device__ __forceinline__ Fe<T> ld_fe(const uint32_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fe<T> r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+
+template <class F> struct FieldIO;
+template <> struct FieldIO<Fp> {
+    static constexpr int WORDS = 8;
+    static __device__ __forceinline__ Fp load_canonical(const uint32_t *p) { return ld_fe<FpTag>(p); }
+};
+template <> struct FieldIO<Fp2> {
+    static constexpr int WORDS = 16;
+    static __device__ __forceinline__ Fp2 load_canonical(const uint32_t *p) { return Fp2{ld_fe<FpTag>(p), ld_fe<FpTag>(p + 8)}; }
+};
+
+// ------------------------------------------------------------------------------ prepare
+// digits[w * n_pad + i] = signed digit d in [-2^(C-1), 2^(C-1)-1] of scalar i for window w.
+template <class F, int C>
+__global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__restrict__ scalars,
+                                                          const uint32_t *__restrict__ points,
+                                                          Affine<F> *__restrict__ pts_m,
+                                                          int16_t *__restrict__ digits, uint32_t n, uint32_t n_pad) {
+    constexpr int W = (255 + C - 1) / C;
+    constexpr int PW = FieldIO<F>::WORDS;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= n) {
+#pragma unroll
+        for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
+        return;
+    }
+    F x = FieldIO<F>::load_canonical(points + (size_t)i * 2 * PW);
+    F y = FieldIO<F>::load_canonical(points + (size_t)i * 2 * PW + PW);
+    const bool inf = x.is_zero() && y.is_zero();
+    pts_m[i] = Affine<F>{fe_to_mont(x), fe_to_mont(y)};
+
+    const Fr s = ld_fe<FrTag>(scalars + (size_t)i * 8);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        constexpr uint32_t mask = (1u << C) - 1u;
+        const int off = w * C, word = off >> 5, sh = off & 31;
+        uint32_t raw = 0;
+        if (word < 8) {
+            raw = s.l[word] >> sh;
+            if (sh + C > 32 && word + 1 < 8) raw |= s.l[word + 1] << (32 - sh);
+        }
+        raw &= mask;
+        uint32_t v = raw + carry;
+        int d;
+        if (v >= (1u << (C - 1))) {
+            d = (int)v - (1 << C);
+            carry = 1;
+        } else {
+            d = (int)v;
+            carry = 0;
+        }
+        if (inf) d = 0;
+        digits[(size_t)w * n_pad + i] = (int16_t)d;
+    }
+}
+
+// ------------------------------------------------------------------------------ block scan
+// Exclusive scan of one value per thread over a block of NT threads (NT multiple of 64).
+// Returns the exclusive prefix; *total receives the block total (same in every thread).
+template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* NT/64+1 in LDS */, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) {
+        uint32_t t = wave_tot[k];
+        if ((uint32_t)k < wid) base += t;
+        tot += t;
+    }
+    *total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------ accumulate
+// grid = (ceil(nb / NT), W); block = NT threads; thread t owns bucket base + t of window w.
+// LDS layout (uint32): cnt[NT] | off[NT + 1] | wave_tot[32] | list[cap]
+template <class F, int NT>
+__global__ __launch_bounds__(NT) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts,
+                                                            const int16_t *__restrict__ digits,
+                                                            Xyzz<F> *__restrict__ buckets, uint32_t n_pad, uint32_t nb,
+                                                            uint32_t chunk, uint32_t cap) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *cnt = lds;
+    uint32_t *off = lds + NT;
+    uint32_t *wave_tot = lds + 2 * NT + 1;
+    uint32_t *list = lds + 2 * NT + 1 + 32;
+
+    const uint32_t t = threadIdx.x, w = blockIdx.y, base = blockIdx.x * NT;
+    const int16_t *dw = digits + (size_t)w * n_pad;
+    constexpr uint32_t GRAN = 8 * NT;  // digits consumed per block-wide uint4 sweep
+
+    Xyzz<F> acc = Xyzz<F>::inf();
+    uint32_t start = 0;
+    while (start < n_pad) {
+        uint32_t len = min(chunk, n_pad - start);
+        uint32_t total;
+        for (;;) {  // shrink the chunk until its entries fit the LDS list (skewed scalars)
+            cnt[t] = 0;
+            __syncthreads();
+            const uint4 *dv = reinterpret_cast<const uint4 *>(dw + start);
+            const uint32_t nvec = len >> 3;
+            for (uint32_t v = t; v < nvec; v += NT) {
+                const uint4 q = dv[v];
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int d = (int)(int16_t)((wd[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+                    if (d != 0) {
+                        const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u - base;
+                        if (j < (uint32_t)NT) atomicAdd(&cnt[j], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t c = cnt[t];
+            const uint32_t ex = block_exclusive_scan<NT>(c, wave_tot, &total);
+            off[t] = ex;
+            if (t == NT - 1) off[NT] = total;
+            if (total <= cap || len <= GRAN) break;
+            len = max(((len >> 1) / GRAN) * GRAN, GRAN);
+            __syncthreads();
+        }
+        // place: cnt[] becomes the per-bucket write cursor
+        cnt[t] = off[t];
+        __syncthreads();
+        {
+            const uint4 *dv = reinterpret_cast<const uint4 *>(dw + start);
+            const uint32_t nvec = len >> 3;
+            for (uint32_t v = t; v < nvec; v += NT) {
+                const uint4 q = dv[v];
+                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int d = (int)(int16_t)((wd[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+                    if (d != 0) {
+                        const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u - base;
+                        if (j < (uint32_t)NT) {
+                            const uint32_t pos = atomicAdd(&cnt[j], 1u);
+                            list[pos] = (start + v * 8 + k) | (d < 0 ? 0x80000000u : 0u);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // accumulate this thread's bucket
+        {
+            const uint32_t k0 = off[t], k1 = off[t + 1];
+            for (uint32_t k = k0; k < k1; k++) {
+                const uint32_t e = list[k];
+                Affine<F> p = pts[e & 0x7fffffffu];
+                if (e >> 31) p.y = fe_neg(p.y);
+                xyzz_add_affine(acc, p);
+            }
+        }
+        __syncthreads();
+        start += len;
+    }
+    if (base + t < nb) buckets[(size_t)w * nb + base + t] = acc;
+}
+
+// ------------------------------------------------------------------------------ reduce
+// out[i] = in[2i] + in[2i+1] over the flattened (window-major) level array.
+template <class F>
+__global__ __launch_bounds__(256) void msm_pair_kernel(const Xyzz<F> *__restrict__ in, Xyzz<F> *__restrict__ out, uint32_t n_out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    Xyzz<F> a = in[2 * (size_t)i];
+    const Xyzz<F> b = in[2 * (size_t)i + 1];
+    xyzz_add(a, b);
+    out[i] = a;
+}
+
+template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
+    Xyzz<F> r;
+    constexpr int NW = sizeof(Xyzz<F>) / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
+    return r;
+}
+template <class F> __device__ __forceinline__ Xyzz<F> wave_sum_xyzz(Xyzz<F> v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Xyzz<F> o = shfl_down_xyzz(v, d);
+        xyzz_add(v, o);
+    }
+    return v;  // valid in lane 0
+}
+
+struct LevelTable {
+    uint32_t level_off[20];  // element offset of level l inside the arena
+    uint32_t nb;             // buckets per window at level 0
+    uint32_t levels;         // log2(nb)
+    uint32_t windows;
+};
+constexpr int ODD_SERIAL = 4;                  // items summed serially per lane
+constexpr int ODD_CHUNK = 64 * ODD_SERIAL;     // odd items per wave
+constexpr int ODD_MAX_CHUNKS = 64;             // nb/2 / ODD_CHUNK <= 64 for nb <= 2^15
+
+// Stage 1: grid = (ODD_MAX_CHUNKS, levels * windows), one wave per block.
+// partial[(g * ODD_MAX_CHUNKS) + chunk] = sum of odd entries [chunk*256, chunk*256+256) of level l, window w.
+template <class F>
+__global__ __launch_bounds__(64) void msm_oddsum1_kernel(const Xyzz<F> *__restrict__ arena, Xyzz<F> *__restrict__ partial, LevelTable lt) {
+    const uint32_t g = blockIdx.y, l = g / lt.windows, w = g % lt.windows;
+    const uint32_t m = lt.nb >> l;  // items per window at level l
+    const uint32_t nodd = m >> 1;
+    const uint32_t chunk = blockIdx.x;
+    if (chunk * ODD_CHUNK >= nodd) return;
+    const Xyzz<F> *lv = arena + lt.level_off[l] + (size_t)w * m;
+    const uint32_t lane = threadIdx.x;
+    Xyzz<F> acc = Xyzz<F>::inf();
+#pragma unroll 1
+    for (int s = 0; s < ODD_SERIAL; s++) {
+        const uint32_t q = chunk * ODD_CHUNK + s * 64 + lane;
+        if (q < nodd) {
+            const Xyzz<F> it = lv[2 * (size_t)q + 1];
+            xyzz_add(acc, it);
+        }
+    }
+    acc = wave_sum_xyzz(acc);
+    if (lane == 0) partial[(size_t)g * ODD_MAX_CHUNKS + chunk] = acc;
+}
+// Stage 2: grid = levels * windows (+ windows blocks that copy the totals); one wave per block.
+// out[w * (levels + 1) + l] = O_{w,l};  out[w * (levels + 1) + levels] = T_w (single item of the last level).
+template <class F>
+__global__ __launch_bounds__(64) void msm_oddsum2_kernel(const Xyzz<F> *__restrict__ arena, const Xyzz<F> *__restrict__ partial,
+                                                         Xyzz<F> *__restrict__ out, LevelTable lt) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    if (g >= lt.levels * lt.windows) {  // totals
+        const uint32_t w = g - lt.levels * lt.windows;
+        if (lane == 0) out[(size_t)w * (lt.levels + 1) + lt.levels] = arena[lt.level_off[lt.levels] + w];
+        return;
+    }
+    const uint32_t l = g / lt.windows, w = g % lt.windows;
+    const uint32_t nodd = (lt.nb >> l) >> 1;
+    const uint32_t nchunks = (nodd + ODD_CHUNK - 1) / ODD_CHUNK;
+    Xyzz<F> acc = Xyzz<F>::inf();
+    if (lane < nchunks) acc = partial[(size_t)g * ODD_MAX_CHUNKS + lane];
+    acc = wave_sum_xyzz(acc);
+    if (lane == 0) out[(size_t)w * (lt.levels + 1) + l] = acc;
+}
+
+// ------------------------------------------------------------------------------ host side
+static int pick_window_bits(size_t n) {
+    if (n <= (1u << 9)) return 8;
+    if (n <= (1u << 14)) return 12;
+    return 16;
+}
+
+template <class F> struct MsmPlanImpl : MsmPlanBase {
+    typedef typename HostOf<F>::type HF;
+    size_t max_n;
+    DevBuf pts_m, digits, arena, partial, out;
+    PinnedBuf h_out;
+
+    static constexpr int MAXC = 16;
+    explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
+        group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
+        size_t n_pad = pad_n(max_n);
+        pts_m.alloc(max_n * sizeof(Affine<F>));
+        // digits: worst case over the window choices available to n <= max_n
+        size_t dig = 0, ar = 0, outn = 0;
+        const int cs[3] = {8, 12, 16};
+        for (int c : cs) {
+            if (c > pick_window_bits(max_n)) continue;
+            size_t W = (255 + c - 1) / c, nb = (size_t)1 << (c - 1);
+            dig = std::max(dig, W * n_pad * sizeof(int16_t));
+            ar = std::max(ar, 2 * W * nb * sizeof(Xyzz<F>));
+            outn = std::max(outn, W * (size_t)c * sizeof(Xyzz<F>));
+        }
+        digits.alloc(dig);
+        arena.alloc(ar);
+        partial.alloc((size_t)32 * 16 * ODD_MAX_CHUNKS * sizeof(Xyzz<F>));
+        out.alloc(outn);
+        h_out.alloc(outn);
+    }
+    static size_t pad_n(size_t n) { return ((n + 4095) / 4096) * 4096; }
+
+    int window_bits(size_t n) const override { return pick_window_bits(n); }
+
+    template <int C> void launch_prepare(const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad, hipStream_t st) {
+        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / 256), dim3(256), 0, st, sc, pt, pts_m.as<Affine<F>>(),
+                           digits.as<int16_t>(), n, n_pad);
+    }
+    template <int NT> void launch_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
+        const uint32_t cap = 12288;
+        uint64_t chunk = (uint64_t)8192 * nb / std::min<uint32_t>(nb, NT);
+        const uint32_t gran = 8 * NT;
+        chunk = std::max<uint64_t>((chunk / gran) * gran, gran);
+        const size_t lds = (2 * NT + 1 + 32 + cap) * sizeof(uint32_t);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F, NT>), dim3((nb + NT - 1) / NT, W), dim3(NT), lds, st, pts_m.as<Affine<F>>(),
+                           digits.as<int16_t>(), arena.as<Xyzz<F>>(), n_pad, nb, (uint32_t)chunk, cap);
+    }
+
+    // Enqueues the GPU pipeline and reads the window/level sums back; returns the XYZZ result.
+    Xyzz<HF> run(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
+        if (n == 0) return Xyzz<HF>::inf();
+        if (n > max_n) throw std::runtime_error("zk_msm: n exceeds the plan's max_n");
+        const int c = pick_window_bits(n);
+        const uint32_t W = (255 + c - 1) / c, nb = 1u << (c - 1), levels = c - 1;
+        const uint32_t n_pad = (uint32_t)pad_n(n);
+        const uint32_t *sc = static_cast<const uint32_t *>(d_scalars), *pt = static_cast<const uint32_t *>(d_points);
+        switch (c) {
+            case 8: launch_prepare<8>(sc, pt, (uint32_t)n, n_pad, st); break;
+            case 12: launch_prepare<12>(sc, pt, (uint32_t)n, n_pad, st); break;
+            default: launch_prepare<16>(sc, pt, (uint32_t)n, n_pad, st); break;
+        }
+        if (nb < 512)
+            launch_accumulate<128>(n_pad, nb, W, st);
+        else
+            launch_accumulate<512>(n_pad, nb, W, st);
+
+        LevelTable lt;
+        lt.nb = nb; lt.levels = levels; lt.windows = W;
+        uint32_t o = 0;
+        for (uint32_t l = 0; l <= levels; l++) {
+            lt.level_off[l] = o;
+            o += W * (nb >> l);
+        }
+        Xyzz<F> *ar = arena.as<Xyzz<F>>();
+        for (uint32_t l = 0; l < levels; l++) {
+            const uint32_t n_out = W * (nb >> (l + 1));
+            hipLaunchKernelGGL((msm_pair_kernel<F>), dim3((n_out + 255) / 256), dim3(256), 0, st, ar + lt.level_off[l],
+                               ar + lt.level_off[l + 1], n_out);
+        }
+        hipLaunchKernelGGL((msm_oddsum1_kernel<F>), dim3(ODD_MAX_CHUNKS, levels * W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), lt);
+        hipLaunchKernelGGL((msm_oddsum2_kernel<F>), dim3(levels * W + W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), out.as<Xyzz<F>>(), lt);
+        const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
+        ZK_HIP(hipMemcpyAsync(h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipGetLastError());
+
+        // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
+        const Xyzz<F> *h = h_out.as<Xyzz<F>>();
+        auto conv = [](const Xyzz<F> &p) { return Xyzz<HF>{HF::from_dev(p.x), HF::from_dev(p.y), HF::from_dev(p.zz), HF::from_dev(p.zzz)}; };
+        Xyzz<HF> acc = Xyzz<HF>::inf();
+        for (int pos = (int)(c * (W - 1) + levels - 1); pos >= 0; pos--) {
+            acc = xyzz_dbl(acc);
+            const uint32_t w = pos / c, l = pos % c;
+            if (l < levels) xyzz_add(acc, conv(h[(size_t)w * (levels + 1) + l]));
+            if (l == 0) xyzz_add(acc, conv(h[(size_t)w * (levels + 1) + levels]));
+        }
+        return acc;
+    }
+
+    int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) override {
+        Xyzz<HF> r = run(d_scalars, d_points, n, st);
+        write_affine<F>(r, out_xy, out_is_inf);
+        return ZK_OK;
+    }
+    int run_partial(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, hipStream_t st) override {
+        Xyzz<HF> r = run(d_scalars, d_points, n, st);
+        memcpy(out_xyzz, &r, sizeof(r));
+        return ZK_OK;
+    }
+};
+
+MsmPlanBase *msm_plan_new(int group, size_t max_n) {
+    if (group == ZK_GROUP_G1) return new MsmPlanImpl<Fp>(max_n);
+    if (group == ZK_GROUP_G2) return new MsmPlanImpl<Fp2>(max_n);
+    return nullptr;
+}
+
+}  // namespace zk

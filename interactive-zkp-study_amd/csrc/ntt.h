@@ -1,0 +1,50 @@
+// ntt.h -- internal interface of the F_r NTT pipeline (ntt.hip).
+#pragma once
+#include <vector>
+#include "common.h"
+#include "field.h"
+#include "host_field.h"
+
+namespace zk {
+
+struct NttPassParams {
+    uint32_t L;          // log2 n
+    uint32_t lp;         // log2 of this pass's digit
+    uint32_t sp;         // log2 stride of the digit (sum of later digits' logs)
+    uint32_t g;          // log2 of adjacent elements/rows carried per tile (coalescing)
+    uint32_t l1;         // final pass: log2 of the first digit (0 when D == 1)
+    uint32_t nmid;       // final pass: number of middle digits (0..2)
+    uint32_t lmid[2];    // final pass: logs of the middle digits, q = 2 first
+    uint32_t tw_shift;   // in-tile twiddle table stride shift (lmax - lp)
+    uint32_t lh;         // low-part bits of the two-level inter-pass twiddle tables
+    uint32_t apply_scale;  // final pass: multiply outputs by `scale` (D == 1 inverse)
+};
+
+// Natural-order in/out radix-2 NTT over F_r of size 2^log_n; omega = 5^((r-1)/n).
+class NttPlan {
+  public:
+    explicit NttPlan(unsigned log_n);
+    // In-place transform of the device buffer (n * 32 bytes, canonical elements).  Enqueues only.
+    void run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st);
+    unsigned log_n() const { return L_; }
+
+  private:
+    void build_tables();
+    void coset_tables(const uint64_t k[4], bool inverse);
+    unsigned L_;
+    std::vector<uint32_t> digits_;  // log2 of each pass's digit, pass 1 first
+    uint32_t lmax_ = 0, lh_ = 0;
+    DevBuf tmp_;
+    // [0] forward, [1] inverse
+    DevBuf tile_tw_[2], twA_[2], twB_[2], twB_scaled_inv_;
+    Fr scale_inv_;  // n^-1 (Montgomery)
+    // coset power tables (two-level), cached for the last (k, direction)
+    DevBuf cosA_, cosB_;
+    uint64_t cos_k_[4] = {0, 0, 0, 0};
+    int cos_dir_ = -1;
+};
+
+// out[i] = (a[i]*b[i] - c[i]) * zinv  on device buffers of canonical F_r elements.
+void fr_quotient(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, hipStream_t st);
+
+}  // namespace zk

@@ -1,0 +1,266 @@
+// ntt.hip -- radix-2 NTT over the BN254 scalar field F_r for gfx950, natural order in and out.
+//
+// Replaces fft / ifft (zkp/plonk/polynomial.py:292-378) and coset_fft / coset_ifft
+// (zkp/plonk/utils.py:145-205).  n = 2^L is factored into D = ceil(L/8) digits n_1..n_D
+// (multi-step / Stockham-style autosort): pass p transforms digit p of every element inside an
+// LDS tile of 2^(l_p) x 8 elements (8 adjacent elements per digit value keep every HBM access a
+// 256-byte run), multiplies by the inter-pass twiddle w_n^(k_p * rem) and writes back; the last
+// pass transforms the contiguous digit and writes to the digit-reversed position, which makes
+// the output natural-order with no separate bit-reversal pass.  Data stays in canonical form:
+// only the twiddles are in Montgomery form (mont_mul(x, w*R) = x*w), so no conversion pass.
+// Each element is read and written once per pass: D * 64 bytes of HBM traffic per element.
+#include <string.h>
+#include "common.h"
+#include "ntt.h"
+
+namespace zk {
+
+constexpr int NTT_NT = 256;  // threads per workgroup
+constexpr int NTT_G = 3;     // log2 adjacent elements per digit value
+
+__device__ __forceinline__ Fr lds_ld(const uint32_t *base, uint32_t stride, uint32_t slot) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = base[i * stride + slot];
+    return r;
+}
+__device__ __forceinline__ void lds_st(uint32_t *base, uint32_t stride, uint32_t slot, const Fr &v) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) base[i * stride + slot] = v.l[i];
+}
+
+// LDS: data[8][tile] (limb-major) | tw[8][2^(lp-1)]
+template <bool FINAL>
+__global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__ in, Fr *__restrict__ out,
+                                                          const Fr *__restrict__ tile_tw, const Fr *__restrict__ twA,
+                                                          const Fr *__restrict__ twB, Fr scale, NttPassParams P) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t t = threadIdx.x;
+    const uint32_t lp = P.lp, g = P.g, G = 1u << g;
+    const uint32_t tile = 1u << (lp + g);
+    const uint32_t ntw = lp ? (1u << (lp - 1)) : 1u;
+    uint32_t *data = lds;
+    uint32_t *tw = lds + 8 * tile;
+
+    for (uint32_t i = t; i < ntw; i += NTT_NT) lds_st(tw, ntw, i, tile_tw[(size_t)i << P.tw_shift]);
+
+    const uint32_t tile_id = blockIdx.x;
+    uint32_t base_addr = 0, mid = 0, k1_base = 0, mid_in = 0;
+    if (!FINAL) {
+        mid = tile_id & ((1u << (P.sp - g)) - 1u);
+        const uint32_t hi = tile_id >> (P.sp - g);
+        base_addr = (hi << (P.sp + lp)) + (mid << g);
+        for (uint32_t e = t; e < tile; e += NTT_NT) {
+            const uint32_t j = e >> g, c = e & (G - 1u);
+            lds_st(data, tile, e, in[(size_t)base_addr + ((size_t)j << P.sp) + c]);
+        }
+    } else {
+        const uint32_t lmid_tot = (P.nmid > 0 ? P.lmid[0] : 0) + (P.nmid > 1 ? P.lmid[1] : 0);
+        mid_in = tile_id & ((1u << lmid_tot) - 1u);
+        k1_base = (tile_id >> lmid_tot) << g;
+        for (uint32_t e = t; e < tile; e += NTT_NT) {
+            const uint32_t c = e >> lp, j = e & ((1u << lp) - 1u);
+            const size_t addr = ((size_t)(k1_base + c) << (P.L - P.l1)) + ((size_t)mid_in << lp) + j;
+            lds_st(data, tile, (j << g) | c, in[addr]);
+        }
+    }
+    __syncthreads();
+
+    // decimation-in-frequency butterflies over the digit index j (slot = j * G + c)
+    for (int s = (int)lp - 1; s >= 0; s--) {
+        const uint32_t half = 1u << s;
+        for (uint32_t b = t; b < (tile >> 1); b += NTT_NT) {
+            const uint32_t c = b & (G - 1u), jj = b >> g;
+            const uint32_t jl = jj & (half - 1u);
+            const uint32_t j = ((jj >> s) << (s + 1)) | jl;
+            const uint32_t sa = (j << g) | c, sb = sa + (half << g);
+            const Fr a = lds_ld(data, tile, sa), bb = lds_ld(data, tile, sb);
+            const Fr w = lds_ld(tw, ntw, jl << (lp - 1 - s));
+            lds_st(data, tile, sa, fe_add(a, bb));
+            lds_st(data, tile, sb, fe_mul(fe_sub(a, bb), w));
+        }
+        __syncthreads();
+    }
+
+    if (!FINAL) {
+        const uint32_t sh = P.L - lp - P.sp;
+        for (uint32_t e = t; e < tile; e += NTT_NT) {
+            const uint32_t k = e >> g, c = e & (G - 1u);
+            const uint32_t jpos = lp ? (__brev(k) >> (32 - lp)) : 0u;
+            Fr x = lds_ld(data, tile, (jpos << g) | c);
+            const uint32_t rem = (mid << g) + c;
+            const uint32_t ex = (k * rem) << sh;
+            const Fr w = fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);
+            x = fe_mul(x, w);
+            out[(size_t)base_addr + ((size_t)k << P.sp) + c] = x;
+        }
+    } else {
+        uint32_t kmid = mid_in, lmid_tot = 0;
+        if (P.nmid == 1) {
+            lmid_tot = P.lmid[0];
+        } else if (P.nmid == 2) {
+            const uint32_t k3 = mid_in & ((1u << P.lmid[1]) - 1u), k2 = mid_in >> P.lmid[1];
+            kmid = k2 | (k3 << P.lmid[0]);
+            lmid_tot = P.lmid[0] + P.lmid[1];
+        }
+        for (uint32_t e = t; e < tile; e += NTT_NT) {
+            const uint32_t k = e >> g, c = e & (G - 1u);
+            const uint32_t jpos = lp ? (__brev(k) >> (32 - lp)) : 0u;
+            Fr x = lds_ld(data, tile, (jpos << g) | c);
+            if (P.apply_scale) x = fe_mul(x, scale);
+            const size_t oidx = (size_t)(k1_base + c) + (((size_t)kmid + ((size_t)k << lmid_tot)) << P.l1);
+            out[oidx] = x;
+        }
+    }
+}
+
+// x[j] *= A[j & mask] * B[j >> lh]   (two-level table of powers g^j, Montgomery form)
+__global__ __launch_bounds__(256) void fr_scale_powers_kernel(Fr *__restrict__ x, const Fr *__restrict__ A, const Fr *__restrict__ B,
+                                                              uint32_t lh, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Fr w = fe_mul(A[i & ((1u << lh) - 1u)], B[i >> lh]);
+    x[i] = fe_mul(x[i], w);
+}
+
+__global__ __launch_bounds__(256) void fr_quotient_kernel(Fr *__restrict__ out, const Fr *__restrict__ a, const Fr *__restrict__ b,
+                                                          const Fr *__restrict__ c, Fr zr, Fr zr2, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // canonical in/out: mont_mul(a,b) = ab/R; times z*R^2 -> ab*z;  mont_mul(c, z*R) = c*z
+    const Fr ab = fe_mul(fe_mul(a[i], b[i]), zr2);
+    out[i] = fe_sub(ab, fe_mul(c[i], zr));
+}
+
+// ------------------------------------------------------------------------------ host side
+static HFr hfr_pow_u64(HFr a, uint64_t e) {
+    uint64_t ee[4] = {e, 0, 0, 0};
+    return fe_pow(a, ee);
+}
+static HFr root_of_unity(unsigned L) {  // w_n = 5^((r-1)/2^L), Montgomery form
+    const uint32_t w28[8] = ZK_FR_ROOT28_M;
+    Fr d;
+    for (int i = 0; i < 8; i++) d.l[i] = w28[i];
+    HFr w = HFr::from_dev(d);
+    for (unsigned i = L; i < ZK_FR_TWO_ADICITY; i++) w = fe_sqr(w);
+    return w;
+}
+static void upload_powers(DevBuf &buf, HFr base, size_t count, const HFr *scale = nullptr) {
+    std::vector<Fr> h(count);
+    HFr cur = scale ? *scale : HFr::one();
+    for (size_t i = 0; i < count; i++) {
+        h[i] = cur.to_dev();
+        cur = fe_mul(cur, base);
+    }
+    buf.alloc(count * sizeof(Fr));
+    ZK_HIP(hipMemcpy(buf.p, h.data(), count * sizeof(Fr), hipMemcpyHostToDevice));
+}
+
+NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
+    if (L_ <= 10) {
+        digits_.push_back(L_);
+    } else {
+        const unsigned D = (L_ + 7) / 8;
+        for (unsigned p = 0; p < D; p++) digits_.push_back(L_ / D + (p < L_ % D ? 1 : 0));
+    }
+    lmax_ = 0;
+    for (uint32_t d : digits_) lmax_ = std::max(lmax_, d);
+    lh_ = (L_ + 1) / 2;
+    build_tables();
+    if (digits_.size() > 1) tmp_.alloc(((size_t)1 << L_) * sizeof(Fr));
+    static bool attr_done = false;
+    if (!attr_done) {
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_done = true;
+    }
+}
+
+void NttPlan::build_tables() {
+    const HFr w = root_of_unity(L_);
+    const HFr wi = fe_inv(w);
+    const HFr ninv = fe_inv(hfe_from_u64<FrTag>((uint64_t)1 << L_));
+    scale_inv_ = ninv.to_dev();
+    for (int dir = 0; dir < 2; dir++) {
+        const HFr base = dir ? wi : w;
+        // in-tile table: w_{2^lmax}^t, t < 2^(lmax-1)
+        const HFr wt = hfr_pow_u64(base, (uint64_t)1 << (L_ - lmax_));
+        upload_powers(tile_tw_[dir], wt, lmax_ ? ((size_t)1 << (lmax_ - 1)) : 1);
+        // two-level inter-pass tables
+        upload_powers(twA_[dir], base, (size_t)1 << lh_);
+        const HFr bh = hfr_pow_u64(base, (uint64_t)1 << lh_);
+        upload_powers(twB_[dir], bh, (size_t)1 << (L_ - lh_));
+        if (dir) upload_powers(twB_scaled_inv_, bh, (size_t)1 << (L_ - lh_), &ninv);
+    }
+}
+
+void NttPlan::coset_tables(const uint64_t k[4], bool inverse) {
+    if (cos_dir_ == (int)inverse && !memcmp(cos_k_, k, 32)) return;
+    HFr kk;
+    memcpy(kk.l, k, 32);
+    kk = fe_to_mont(kk);
+    if (inverse) kk = fe_inv(kk);
+    upload_powers(cosA_, kk, (size_t)1 << lh_);
+    upload_powers(cosB_, hfr_pow_u64(kk, (uint64_t)1 << lh_), (size_t)1 << (L_ - lh_));
+    memcpy(cos_k_, k, 32);
+    cos_dir_ = (int)inverse;
+}
+
+void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st) {
+    const size_t n = (size_t)1 << L_;
+    Fr *data = static_cast<Fr *>(d_data);
+    const int dir = inverse ? 1 : 0;
+    const unsigned D = (unsigned)digits_.size();
+    const unsigned blocks_sc = (unsigned)((n + 255) / 256);
+    if (coset_shift && !inverse) {
+        coset_tables(coset_shift, false);
+        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_.as<Fr>(), cosB_.as<Fr>(), lh_, n);
+    }
+    if (L_ > 0 || inverse) {
+        uint32_t sp = L_;
+        for (unsigned p = 0; p < D; p++) {
+            const uint32_t lp = digits_[p];
+            sp -= lp;
+            NttPassParams P;
+            memset(&P, 0, sizeof(P));
+            P.L = L_; P.lp = lp; P.sp = sp; P.lh = lh_;
+            P.tw_shift = lmax_ - lp;
+            const bool final_pass = (p == D - 1);
+            P.g = (D == 1) ? 0 : NTT_G;
+            const Fr *src = (p == 0) ? data : tmp_.as<Fr>();
+            Fr *dst = final_pass ? data : tmp_.as<Fr>();
+            const uint32_t tile = 1u << (lp + P.g);
+            const size_t lds = ((size_t)8 * tile + 8 * (lp ? (1u << (lp - 1)) : 1u)) * sizeof(uint32_t);
+            const unsigned blocks = (unsigned)(n >> (lp + P.g));
+            if (!final_pass) {
+                const Fr *B = (inverse && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
+                hipLaunchKernelGGL((ntt_pass_kernel<false>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                                   twA_[dir].as<Fr>(), B, scale_inv_, P);
+            } else {
+                P.l1 = (D == 1) ? 0 : digits_[0];
+                P.nmid = D > 2 ? D - 2 : 0;
+                for (unsigned q = 0; q < P.nmid; q++) P.lmid[q] = digits_[1 + q];
+                P.apply_scale = (inverse && D == 1) ? 1 : 0;
+                hipLaunchKernelGGL((ntt_pass_kernel<true>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                                   twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
+            }
+        }
+    }
+    if (coset_shift && inverse) {
+        coset_tables(coset_shift, true);
+        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_.as<Fr>(), cosB_.as<Fr>(), lh_, n);
+    }
+    ZK_HIP(hipGetLastError());
+}
+
+void fr_quotient(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, hipStream_t st) {
+    HFr z;
+    memcpy(z.l, zinv, 32);
+    const HFr zr = fe_to_mont(z), zr2 = fe_to_mont(zr);
+    if (n == 0) return;
+    hipLaunchKernelGGL(fr_quotient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<Fr *>(d_out),
+                       static_cast<const Fr *>(d_a), static_cast<const Fr *>(d_b), static_cast<const Fr *>(d_c), zr.to_dev(), zr2.to_dev(), n);
+    ZK_HIP(hipGetLastError());
+}
+
+}  // namespace zk
