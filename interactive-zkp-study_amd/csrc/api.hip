@@ -190,6 +190,16 @@ int zk_msm_plan_destroy(zk_msm_plan *plan) {
     delete plan;
     return ZK_OK;
 }
+int zk_msm_plan_profile(zk_msm_plan *plan, int enable) {
+    if (!plan) return ZK_ERR_INVALID;
+    plan->impl->profile = enable != 0;
+    return ZK_OK;
+}
+int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[3]) {
+    if (!plan || !out_ms) return ZK_ERR_INVALID;
+    for (int i = 0; i < 3; i++) out_ms[i] = plan->impl->stage_ms[i];
+    return ZK_OK;
+}
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n) { return plan ? plan->impl->window_bits(n) : ZK_ERR_INVALID; }
 int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, void *stream) {
     return guarded([&] {

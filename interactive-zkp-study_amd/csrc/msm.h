@@ -9,6 +9,8 @@ namespace zk {
 
 struct MsmPlanBase {
     int group = 0;
+    bool profile = false;                  // record HIP events around the pipeline stages
+    float stage_ms[3] = {0.f, 0.f, 0.f};   // last run: prepare, accumulate, reduce (device time)
     virtual ~MsmPlanBase() {}
     virtual int window_bits(size_t n) const = 0;
     virtual int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) = 0;

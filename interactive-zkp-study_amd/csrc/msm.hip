@@ -299,6 +299,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     size_t max_n;
     DevBuf pts_m, digits, arena, partial, out;
     PinnedBuf h_out;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
 
     static constexpr int MAXC = 16;
     explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
@@ -321,7 +322,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         out.alloc(outn);
         h_out.alloc(outn);
     }
+    ~MsmPlanImpl() override {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     static size_t pad_n(size_t n) { return ((n + 4095) / 4096) * 4096; }
+    void mark(int i, hipStream_t st) {
+        if (!profile) return;
+        if (!ev[i]) ZK_HIP(hipEventCreate(&ev[i]));
+        ZK_HIP(hipEventRecord(ev[i], st));
+    }
 
     int window_bits(size_t n) const override { return pick_window_bits(n); }
 
@@ -347,15 +357,18 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const uint32_t W = (255 + c - 1) / c, nb = 1u << (c - 1), levels = c - 1;
         const uint32_t n_pad = (uint32_t)pad_n(n);
         const uint32_t *sc = static_cast<const uint32_t *>(d_scalars), *pt = static_cast<const uint32_t *>(d_points);
+        mark(0, st);
         switch (c) {
             case 8: launch_prepare<8>(sc, pt, (uint32_t)n, n_pad, st); break;
             case 12: launch_prepare<12>(sc, pt, (uint32_t)n, n_pad, st); break;
             default: launch_prepare<16>(sc, pt, (uint32_t)n, n_pad, st); break;
         }
+        mark(1, st);
         if (nb < 512)
             launch_accumulate<128>(n_pad, nb, W, st);
         else
             launch_accumulate<512>(n_pad, nb, W, st);
+        mark(2, st);
 
         LevelTable lt;
         lt.nb = nb; lt.levels = levels; lt.windows = W;
@@ -372,10 +385,14 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         }
         hipLaunchKernelGGL((msm_oddsum1_kernel<F>), dim3(ODD_MAX_CHUNKS, levels * W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), lt);
         hipLaunchKernelGGL((msm_oddsum2_kernel<F>), dim3(levels * W + W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), out.as<Xyzz<F>>(), lt);
+        mark(3, st);
         const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
         ZK_HIP(hipMemcpyAsync(h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
         ZK_HIP(hipGetLastError());
+        if (profile) {
+            for (int i = 0; i < 3; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]));
+        }
 
         // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
         const Xyzz<F> *h = h_out.as<Xyzz<F>>();

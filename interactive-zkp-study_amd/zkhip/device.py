@@ -1,0 +1,96 @@
+"""Device-resident entry points: thin handle classes over the plan API of include/zkhip.h.
+
+Buffers are DEVICE pointers (e.g. torch tensor .data_ptr()); streams are raw hipStream_t
+handles (e.g. torch.cuda.current_stream().cuda_stream).  Used by bench.py and the at-scale
+prover; the list-based facade (zkhip.field / groth16 / plonk) goes through the host-buffer calls.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .field import limbs_to_g1, limbs_to_g2
+
+
+class MsmPlan:
+    """Workspace + pipeline for G1/G2 MSMs of up to max_n points (zk_msm_plan_*)."""
+
+    def __init__(self, group, max_n):
+        self.group = group
+        self.max_n = int(max_n)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().zk_msm_plan_create(group, self.max_n, ctypes.byref(self._h)))
+        self._limbs = 8 if group == _lib.GROUP_G1 else 16
+
+    def close(self):
+        if self._h:
+            _lib.load().zk_msm_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def window_bits(self, n):
+        return _lib.load().zk_msm_plan_window_bits(self._h, n)
+
+    def set_profiling(self, enable):
+        _lib.check(_lib.load().zk_msm_plan_profile(self._h, 1 if enable else 0))
+
+    def stage_ms(self):
+        """Device time of the last run: (prepare, accumulate, reduce) in ms (HIP events on the
+        pipeline's stream; needs set_profiling(True))."""
+        out = (ctypes.c_float * 3)()
+        _lib.check(_lib.load().zk_msm_plan_stage_ms(self._h, out))
+        return tuple(float(v) for v in out)
+
+    def run_limbs(self, d_scalars, d_points, n, stream=0):
+        """-> (uint64[8|16] canonical affine limbs, is_inf)."""
+        out = np.zeros(self._limbs, dtype=np.uint64)
+        inf = ctypes.c_int(0)
+        _lib.check(_lib.load().zk_msm_dev(self._h, d_scalars, d_points, n, _lib.ptr(out), ctypes.byref(inf), stream))
+        return out, bool(inf.value)
+
+    def run(self, d_scalars, d_points, n, stream=0):
+        out, inf = self.run_limbs(d_scalars, d_points, n, stream)
+        if inf:
+            return None
+        return (limbs_to_g1(out) if self.group == _lib.GROUP_G1 else limbs_to_g2(out))[0]
+
+    def run_partial(self, d_scalars, d_points, n, stream=0):
+        """-> uint64[16|32]: this device's partial sum in XYZZ Montgomery limbs (for folding)."""
+        out = np.zeros(2 * self._limbs, dtype=np.uint64)
+        _lib.check(_lib.load().zk_msm_dev_partial(self._h, d_scalars, d_points, n, _lib.ptr(out), stream))
+        return out
+
+
+class NttPlan:
+    """Twiddle tables + scratch for in-place device NTTs of size 2^log_n (zk_ntt_plan_*)."""
+
+    def __init__(self, log_n):
+        self.log_n = int(log_n)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().zk_ntt_plan_create(self.log_n, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.load().zk_ntt_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, d_data, inverse=False, coset_shift=None, stream=0):
+        k = None if coset_shift is None else _lib.ints_to_limbs([int(coset_shift)])
+        _lib.check(_lib.load().zk_ntt_dev(self._h, d_data, 1 if inverse else 0, None if k is None else _lib.ptr(k), stream))
+
+
+def fr_quotient(d_out, d_a, d_b, d_c, zinv, n, stream=0):
+    """out[i] = (a[i]*b[i] - c[i]) * zinv on device buffers (zk_fr_quotient_dev)."""
+    z = _lib.ints_to_limbs([int(zinv)])
+    _lib.check(_lib.load().zk_fr_quotient_dev(d_out, d_a, d_b, d_c, _lib.ptr(z), n, stream))
