@@ -121,7 +121,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    stage = np.zeros(3)
+    stage = np.zeros(4)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -149,8 +149,8 @@ def main():
     verified = (got == expect)
 
     extra = {"verified_closed_form": bool(verified), "window_bits": plan.window_bits(n),
-             "stage_ms": {"prepare": round(float(stage[0]), 4), "accumulate": round(float(stage[1]), 4),
-                          "reduce": round(float(stage[2]), 4)}}
+             "stage_ms": {"prepare": round(float(stage[0]), 4), "sort": round(float(stage[1]), 4), "accumulate": round(float(stage[2]), 4),
+                          "reduce": round(float(stage[3]), 4)}}
 
     # ---- secondary: NTT forward + inverse round trip (BASELINE.json configs[2])
     if args.ntt_log_n and rank == 0:
@@ -196,7 +196,7 @@ def main():
 
     if rank == 0:
         total_points = n * world * args.steps
-        acc_ms = float(stage[1])
+        acc_ms = float(stage[2])
         achieved = G1_BYTES_PER_POINT * n / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -213,7 +213,7 @@ def main():
             "config": {"workload": "BN254 G1 MSM, 2^%d uniform random scalars x random points per GPU, inputs resident in HBM "
                                    "(BASELINE.json configs[1])" % args.log_n,
                        "points_per_gpu": n, "sharding": "point chunks, 1 all-gather of 128-B partials" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp,512>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "integer-ALU-bound kernel: ~160 modular multiplications per point; see DESIGN.md"},
             "cpu_baseline": cpu,

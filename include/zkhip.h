@@ -68,9 +68,9 @@ int zk_msm_plan_destroy(zk_msm_plan *plan);
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n);
 /* Measurement hooks: with profiling enabled each run records HIP events on the pipeline's own
  * stream around its stages; zk_msm_plan_stage_ms returns the last run's device time in ms for
- * {prepare, bucket accumulation, bucket reduction}. */
+ * {prepare, bucket sort, bucket accumulation, bucket reduction}. */
 int zk_msm_plan_profile(zk_msm_plan *plan, int enable);
-int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[3]);
+int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[4]);
 /* Runs the whole MSM on `stream`; returns after the (tiny) window sums have been read back
  * and folded, i.e. the result is final.  out_xy: 8 (G1) or 16 (G2) limbs on the HOST. */
 int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n,

@@ -195,9 +195,9 @@ int zk_msm_plan_profile(zk_msm_plan *plan, int enable) {
     plan->impl->profile = enable != 0;
     return ZK_OK;
 }
-int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[3]) {
+int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[4]) {
     if (!plan || !out_ms) return ZK_ERR_INVALID;
-    for (int i = 0; i < 3; i++) out_ms[i] = plan->impl->stage_ms[i];
+    for (int i = 0; i < 4; i++) out_ms[i] = plan->impl->stage_ms[i];
     return ZK_OK;
 }
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n) { return plan ? plan->impl->window_bits(n) : ZK_ERR_INVALID; }

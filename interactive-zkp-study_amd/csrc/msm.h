@@ -10,13 +10,17 @@ namespace zk {
 struct MsmPlanBase {
     int group = 0;
     bool profile = false;                  // record HIP events around the pipeline stages
-    float stage_ms[3] = {0.f, 0.f, 0.f};   // last run: prepare, accumulate, reduce (device time)
+    float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};  // last run: prepare, bucket sort, accumulate, reduce (device ms)
     virtual ~MsmPlanBase() {}
     virtual int window_bits(size_t n) const = 0;
     virtual int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) = 0;
     virtual int run_partial(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, hipStream_t st) = 0;
 };
-MsmPlanBase *msm_plan_new(int group, size_t max_n);
+MsmPlanBase *msm_plan_new_g1(size_t max_n);
+MsmPlanBase *msm_plan_new_g2(size_t max_n);
+inline MsmPlanBase *msm_plan_new(int group, size_t max_n) {
+    return group == ZK_GROUP_G1 ? msm_plan_new_g1(max_n) : group == ZK_GROUP_G2 ? msm_plan_new_g2(max_n) : nullptr;
+}
 
 // Host XYZZ (Montgomery) -> canonical affine limbs; infinity -> zeros + flag.
 inline void write_fe_canonical(const HFp &a, uint64_t *out) {

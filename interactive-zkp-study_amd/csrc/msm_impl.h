@@ -1,4 +1,4 @@
-// msm.hip -- Pippenger multi-scalar multiplication on BN254 G1 / G2 for gfx950.
+// msm_impl.h -- Pippenger multi-scalar multiplication on BN254 G1 / G2 for gfx950.
 //
 // Replaces the reference's scalar-mul-and-add loops (zkp/plonk/kzg.py:59-65,
 // zkp/groth16/proving.py:23-75).  Pipeline (all kernels on one stream, no host sync until the
@@ -16,6 +16,7 @@
 //                sum_j j*B_j = sum_l 2^l * O_l.
 //   fold (host)  the W*(c) window/level sums (32 KiB) are read back and combined by one
 //                254-doubling Horner pass on the host (a single GPU thread would be latency-bound).
+#pragma once
 #include <vector>
 #include "common.h"
 #include "curve.h"
@@ -116,92 +117,129 @@ template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint3
     return base + inc - v;
 }
 
-// ------------------------------------------------------------------------------ accumulate
-// grid = (ceil(nb / NT), W); block = NT threads; thread t owns bucket base + t of window w.
-// LDS layout (uint32): cnt[NT] | off[NT + 1] | wave_tot[32] | list[cap]
-template <class F, int NT>
-__global__ __launch_bounds__(NT) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts,
-                                                            const int16_t *__restrict__ digits,
-                                                            Xyzz<F> *__restrict__ buckets, uint32_t n_pad, uint32_t nb,
-                                                            uint32_t chunk, uint32_t cap) {
-    extern __shared__ uint32_t lds[];
-    uint32_t *cnt = lds;
-    uint32_t *off = lds + NT;
-    uint32_t *wave_tot = lds + 2 * NT + 1;
-    uint32_t *list = lds + 2 * NT + 1 + 32;
+// ------------------------------------------------------------------------------ bucket sort
+// Counting sort of the (window, bucket) -> point-index lists, staged through LDS counters.
+// grid = (ceil(nb / SORT_BPG), W); one workgroup owns SORT_BPG consecutive buckets of one window
+// and streams that window's digit row (L2-resident: a row is n*2 bytes and is shared by the
+// nb/SORT_BPG workgroups of the window).
+//   COUNT pass: LDS-atomic histogram -> counts[flat bucket], group_total[group]
+//   PLACE pass: counts -> exclusive offsets (block scan + group base), LDS-atomic cursors,
+//               entries (point index | sign << 31) written to sorted[] (each workgroup's output
+//               region is one contiguous, L2-resident span).
+constexpr int SORT_NT = 1024;
+constexpr int SORT_BPG = 2048;
 
-    const uint32_t t = threadIdx.x, w = blockIdx.y, base = blockIdx.x * NT;
-    const int16_t *dw = digits + (size_t)w * n_pad;
-    constexpr uint32_t GRAN = 8 * NT;  // digits consumed per block-wide uint4 sweep
-
-    Xyzz<F> acc = Xyzz<F>::inf();
-    uint32_t start = 0;
-    while (start < n_pad) {
-        uint32_t len = min(chunk, n_pad - start);
+template <bool PLACE>
+__global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__restrict__ digits, uint32_t *__restrict__ counts,
+                                                           uint32_t *__restrict__ bucket_off, const uint32_t *__restrict__ group_base,
+                                                           uint32_t *__restrict__ group_total, uint32_t *__restrict__ sorted,
+                                                           uint32_t n_pad, uint32_t nb) {
+    __shared__ uint32_t cnt[SORT_BPG];
+    __shared__ uint32_t wave_tot[SORT_NT / 64 + 1];
+    const uint32_t t = threadIdx.x, g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+    const uint32_t base = g * SORT_BPG;
+    const uint32_t nloc = min((uint32_t)SORT_BPG, nb - base);
+    const size_t flat0 = (size_t)w * nb + base;
+    if (!PLACE) {
+        cnt[2 * t] = 0;
+        cnt[2 * t + 1] = 0;
+    } else {
+        const uint32_t c0 = (2 * t < nloc) ? counts[flat0 + 2 * t] : 0u;
+        const uint32_t c1 = (2 * t + 1 < nloc) ? counts[flat0 + 2 * t + 1] : 0u;
         uint32_t total;
-        for (;;) {  // shrink the chunk until its entries fit the LDS list (skewed scalars)
-            cnt[t] = 0;
-            __syncthreads();
-            const uint4 *dv = reinterpret_cast<const uint4 *>(dw + start);
-            const uint32_t nvec = len >> 3;
-            for (uint32_t v = t; v < nvec; v += NT) {
-                const uint4 q = dv[v];
-                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int d = (int)(int16_t)((wd[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
-                    if (d != 0) {
-                        const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u - base;
-                        if (j < (uint32_t)NT) atomicAdd(&cnt[j], 1u);
-                    }
-                }
-            }
-            __syncthreads();
-            const uint32_t c = cnt[t];
-            const uint32_t ex = block_exclusive_scan<NT>(c, wave_tot, &total);
-            off[t] = ex;
-            if (t == NT - 1) off[NT] = total;
-            if (total <= cap || len <= GRAN) break;
-            len = max(((len >> 1) / GRAN) * GRAN, GRAN);
-            __syncthreads();
-        }
-        // place: cnt[] becomes the per-bucket write cursor
-        cnt[t] = off[t];
-        __syncthreads();
-        {
-            const uint4 *dv = reinterpret_cast<const uint4 *>(dw + start);
-            const uint32_t nvec = len >> 3;
-            for (uint32_t v = t; v < nvec; v += NT) {
-                const uint4 q = dv[v];
-                const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int d = (int)(int16_t)((wd[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
-                    if (d != 0) {
-                        const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u - base;
-                        if (j < (uint32_t)NT) {
-                            const uint32_t pos = atomicAdd(&cnt[j], 1u);
-                            list[pos] = (start + v * 8 + k) | (d < 0 ? 0x80000000u : 0u);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // accumulate this thread's bucket
-        {
-            const uint32_t k0 = off[t], k1 = off[t + 1];
-            for (uint32_t k = k0; k < k1; k++) {
-                const uint32_t e = list[k];
-                Affine<F> p = pts[e & 0x7fffffffu];
-                if (e >> 31) p.y = fe_neg(p.y);
-                xyzz_add_affine(acc, p);
-            }
-        }
-        __syncthreads();
-        start += len;
+        const uint32_t ex = block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total) + group_base[w * G + g];
+        cnt[2 * t] = ex;
+        cnt[2 * t + 1] = ex + c0;
+        if (2 * t < nloc) bucket_off[flat0 + 2 * t] = ex;
+        if (2 * t + 1 < nloc) bucket_off[flat0 + 2 * t + 1] = ex + c0;
     }
-    if (base + t < nb) buckets[(size_t)w * nb + base + t] = acc;
+    __syncthreads();
+    const uint4 *dv = reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad);
+    const uint32_t nvec = n_pad >> 3;
+    for (uint32_t v = t; v < nvec; v += SORT_NT) {
+        const uint4 q = dv[v];
+        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int d = (int)(int16_t)((wd[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+            if (d != 0) {
+                const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u - base;
+                if (j < nloc) {
+                    const uint32_t pos = atomicAdd(&cnt[j], 1u);
+                    if (PLACE) sorted[pos] = (v * 8 + k) | (d < 0 ? 0x80000000u : 0u);
+                }
+            }
+        }
+    }
+    if (!PLACE) {
+        __syncthreads();
+        const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
+        if (2 * t < nloc) counts[flat0 + 2 * t] = c0;
+        if (2 * t + 1 < nloc) counts[flat0 + 2 * t + 1] = c1;
+        uint32_t total;
+        (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);
+        if (t == 0) group_total[w * G + g] = total;
+    }
+}
+
+// Exclusive scan of the (<= 256) group totals; one workgroup.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void msm_groupscan_kernel(const uint32_t *__restrict__ group_total, uint32_t *__restrict__ group_base,
+                                                            uint32_t ngroups) {
+    __shared__ uint32_t wave_tot[8];
+    const uint32_t t = threadIdx.x;
+    const uint32_t v = t < ngroups ? group_total[t] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<256>(v, wave_tot, &total);
+    if (t < ngroups) group_base[t] = ex;
+}
+
+// ------------------------------------------------------------------------------ accumulate
+// One thread per bucket over the flattened (window-major) bucket array.  The 256 buckets of a
+// workgroup are ranked by size in LDS so that the lanes of a wavefront own buckets of (nearly)
+// equal length; each thread then adds its points in XYZZ mixed coordinates (8M+2S per point),
+// with the next (index, point) pair fetched while the current addition runs.
+template <class F>
+__global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+                                                             const uint32_t *__restrict__ counts,
+                                                             const uint32_t *__restrict__ bucket_off, Xyzz<F> *__restrict__ buckets,
+                                                             uint32_t nbuckets) {
+    __shared__ uint32_t s_cnt[256];
+    __shared__ uint32_t s_perm[256];
+    const uint32_t t = threadIdx.x, b0 = blockIdx.x * 256;
+    const uint32_t c = (b0 + t < nbuckets) ? counts[b0 + t] : 0u;
+    s_cnt[t] = c;
+    __syncthreads();
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u < 256; u++) {
+        const uint32_t cu = s_cnt[u];
+        rank += (cu > c || (cu == c && u < t)) ? 1u : 0u;
+    }
+    s_perm[rank] = t;
+    __syncthreads();
+    const uint32_t mine = s_perm[t];
+    const uint32_t b = b0 + mine;
+    if (b >= nbuckets) return;
+    const uint32_t len = s_cnt[mine];
+    Xyzz<F> acc = Xyzz<F>::inf();
+    if (len) {
+        const uint32_t *lst = sorted + bucket_off[b];
+        uint32_t e = lst[0];
+        Affine<F> p = pts[e & 0x7fffffffu];
+        for (uint32_t k = 1; k <= len; k++) {
+            uint32_t e2 = 0;
+            Affine<F> p2 = p;
+            if (k < len) {
+                e2 = lst[k];
+                p2 = pts[e2 & 0x7fffffffu];
+            }
+            if (e >> 31) p.y = fe_neg(p.y);
+            xyzz_add_affine(acc, p);
+            e = e2;
+            p = p2;
+        }
+    }
+    buckets[b] = acc;
 }
 
 // ------------------------------------------------------------------------------ reduce
@@ -297,9 +335,9 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, arena, partial, out;
+    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, arena, partial, out;
     PinnedBuf h_out;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
 
     static constexpr int MAXC = 16;
     explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
@@ -317,6 +355,11 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             outn = std::max(outn, W * (size_t)c * sizeof(Xyzz<F>));
         }
         digits.alloc(dig);
+        sorted.alloc(dig * 2);  // one 4-byte entry per (window, point)
+        counts.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
+        bucket_off.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
+        group_tot.alloc(256 * sizeof(uint32_t));
+        group_base.alloc(256 * sizeof(uint32_t));
         arena.alloc(ar);
         partial.alloc((size_t)32 * 16 * ODD_MAX_CHUNKS * sizeof(Xyzz<F>));
         out.alloc(outn);
@@ -339,14 +382,19 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / 256), dim3(256), 0, st, sc, pt, pts_m.as<Affine<F>>(),
                            digits.as<int16_t>(), n, n_pad);
     }
-    template <int NT> void launch_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
-        const uint32_t cap = 12288;
-        uint64_t chunk = (uint64_t)8192 * nb / std::min<uint32_t>(nb, NT);
-        const uint32_t gran = 8 * NT;
-        chunk = std::max<uint64_t>((chunk / gran) * gran, gran);
-        const size_t lds = (2 * NT + 1 + 32 + cap) * sizeof(uint32_t);
-        hipLaunchKernelGGL((msm_accumulate_kernel<F, NT>), dim3((nb + NT - 1) / NT, W), dim3(NT), lds, st, pts_m.as<Affine<F>>(),
-                           digits.as<int16_t>(), arena.as<Xyzz<F>>(), n_pad, nb, (uint32_t)chunk, cap);
+    void launch_sort_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
+        const uint32_t G = (nb + SORT_BPG - 1) / SORT_BPG;
+        if (G * W > 256) throw std::runtime_error("zk_msm: too many bucket groups");
+        const dim3 grid(G, W);
+        hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), counts.as<uint32_t>(),
+                           bucket_off.as<uint32_t>(), group_base.as<uint32_t>(), group_tot.as<uint32_t>(), sorted.as<uint32_t>(), n_pad, nb);
+        hipLaunchKernelGGL((msm_groupscan_kernel<0>), dim3(1), dim3(256), 0, st, group_tot.as<uint32_t>(), group_base.as<uint32_t>(), G * W);
+        hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), counts.as<uint32_t>(),
+                           bucket_off.as<uint32_t>(), group_base.as<uint32_t>(), group_tot.as<uint32_t>(), sorted.as<uint32_t>(), n_pad, nb);
+        mark(2, st);
+        const uint32_t nbuckets = W * nb;
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 255) / 256), dim3(256), 0, st, pts_m.as<Affine<F>>(),
+                           sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), arena.as<Xyzz<F>>(), nbuckets);
     }
 
     // Enqueues the GPU pipeline and reads the window/level sums back; returns the XYZZ result.
@@ -364,11 +412,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             default: launch_prepare<16>(sc, pt, (uint32_t)n, n_pad, st); break;
         }
         mark(1, st);
-        if (nb < 512)
-            launch_accumulate<128>(n_pad, nb, W, st);
-        else
-            launch_accumulate<512>(n_pad, nb, W, st);
-        mark(2, st);
+        launch_sort_accumulate(n_pad, nb, W, st);
+        mark(3, st);
 
         LevelTable lt;
         lt.nb = nb; lt.levels = levels; lt.windows = W;
@@ -385,13 +430,13 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         }
         hipLaunchKernelGGL((msm_oddsum1_kernel<F>), dim3(ODD_MAX_CHUNKS, levels * W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), lt);
         hipLaunchKernelGGL((msm_oddsum2_kernel<F>), dim3(levels * W + W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), out.as<Xyzz<F>>(), lt);
-        mark(3, st);
+        mark(4, st);
         const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
         ZK_HIP(hipMemcpyAsync(h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
         ZK_HIP(hipGetLastError());
         if (profile) {
-            for (int i = 0; i < 3; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]));
+            for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]));
         }
 
         // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
@@ -418,11 +463,5 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         return ZK_OK;
     }
 };
-
-MsmPlanBase *msm_plan_new(int group, size_t max_n) {
-    if (group == ZK_GROUP_G1) return new MsmPlanImpl<Fp>(max_n);
-    if (group == ZK_GROUP_G2) return new MsmPlanImpl<Fp2>(max_n);
-    return nullptr;
-}
 
 }  // namespace zk

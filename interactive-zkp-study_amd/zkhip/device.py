@@ -40,9 +40,9 @@ class MsmPlan:
         _lib.check(_lib.load().zk_msm_plan_profile(self._h, 1 if enable else 0))
 
     def stage_ms(self):
-        """Device time of the last run: (prepare, accumulate, reduce) in ms (HIP events on the
+        """Device time of the last run: (prepare, sort, accumulate, reduce) in ms (HIP events on the
         pipeline's stream; needs set_profiling(True))."""
-        out = (ctypes.c_float * 3)()
+        out = (ctypes.c_float * 4)()
         _lib.check(_lib.load().zk_msm_plan_stage_ms(self._h, out))
         return tuple(float(v) for v in out)
 
