@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void msm_groupscan_kernel(const uint32_t *__re
 // equal length; each thread then adds its points in XYZZ mixed coordinates (8M+2S per point),
 // with the next (index, point) pair fetched while the current addition runs.
 template <class F>
-__global__ __launch_bounds__(256) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(256, (sizeof(F) <= 32 ? 3 : 1)) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts,
                                                              const uint32_t *__restrict__ bucket_off, Xyzz<F> *__restrict__ buckets,
                                                              uint32_t nbuckets) {

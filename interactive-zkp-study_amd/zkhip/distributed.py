@@ -30,9 +30,9 @@ def all_gather_partials(partial, device=None, group=None):
     t = torch.from_numpy(np.ascontiguousarray(partial).view(np.int64).copy())
     if device is not None:
         t = t.to(device)
-    out = torch.empty((world, t.numel()), dtype=torch.int64, device=t.device)
+    out = torch.empty(world * t.numel(), dtype=torch.int64, device=t.device)  # flat: gloo and RCCL both accept it
     dist.all_gather_into_tensor(out, t, group=group)
-    return out.cpu().numpy().view(np.uint64)
+    return out.cpu().numpy().view(np.uint64).reshape(world, -1)
 
 
 def fold_partials(group_id, partials):

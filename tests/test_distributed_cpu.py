@@ -1,0 +1,52 @@
+"""World-size-2 `gloo` test (CPU) of the multi-GPU MSM path used by bench.py --gpus N:
+shard the points by contiguous chunks, all-gather the 128-byte partial sums, fold in rank order.
+On CPU the per-rank partial comes from the oracle (test infrastructure); the sharding, the
+collective and the host fold (zk_msm_fold_partials) are the product code under test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, n, ret):
+    sys.path.insert(0, os.path.join(HERE, "..", "interactive-zkp-study_amd"))
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    sys.path.insert(0, HERE)
+    import c_oracle as co
+    import py_ref as o
+    from test_abi import xyzz_partial_g1
+    from zkhip import _lib
+    from zkhip.distributed import shard_range, sharded_msm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(99)  # same data on every rank; each rank uses its own chunk
+        sc = co.to_limbs([int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)])
+        ks = co.to_limbs([int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)])
+        pts = co.g1_fixed_base_arr(o.G1, ks)
+        lo, hi = shard_range(n, rank, world)
+        local = co.g1_from_arr(co.g1_msm_arr(sc[lo:hi], pts[lo:hi]))[0] if hi > lo else None
+        got = sharded_msm(_lib.GROUP_G1, xyzz_partial_g1(local))
+        full = co.g1_from_arr(co.g1_msm_arr(sc, pts))[0]
+        ok = (got is None and full is None) or (got is not None and (int(got[0]), int(got[1])) == full)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 37])
+def test_sharded_msm_gloo_world2(n):
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + n
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

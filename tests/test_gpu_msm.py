@@ -1,0 +1,183 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP MSM pipeline, called through the C ABI,
+against the oracle on the same seeded inputs -- bit-exact -- plus size-independent properties at the
+BASELINE.json size (2^20)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import c_oracle as co
+import py_ref as o
+from helpers import limb_row, rand_fr_limbs, rand_g1_limbs, rand_g2_limbs
+from zkhip import _lib
+from zkhip.device import MsmPlan
+from zkhip.distributed import fold_partials
+
+pytestmark = pytest.mark.gpu
+
+
+def msm_g1(S, Pts):
+    out = np.zeros(8, dtype=np.uint64)
+    inf = ctypes.c_int(-1)
+    rc = _lib.load().zk_msm_g1(_lib.ptr(S), _lib.ptr(Pts), S.shape[0], _lib.ptr(out), ctypes.byref(inf))
+    assert rc == 0, _lib.load().zk_last_error()
+    assert inf.value == (0 if out.any() else 1)
+    return out
+
+
+def msm_g2(S, Pts):
+    out = np.zeros(16, dtype=np.uint64)
+    inf = ctypes.c_int(-1)
+    rc = _lib.load().zk_msm_g2(_lib.ptr(S), _lib.ptr(Pts), S.shape[0], _lib.ptr(out), ctypes.byref(inf))
+    assert rc == 0, _lib.load().zk_last_error()
+    return out
+
+
+# sizes straddle the window-width switches (c = 8 | 12 | 16 at n = 512 / 16384) and block edges
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 255, 256, 257, 512, 513, 1000, 4095, 4096, 4097, 16384, 16385, 40000])
+def test_g1_msm_bit_exact_vs_oracle(n):
+    rng = np.random.default_rng(1000 + n)
+    S = rand_fr_limbs(rng, n)
+    Pts, _ = rand_g1_limbs(rng, n)
+    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_arr(S, Pts))
+
+
+def test_g1_msm_edge_scalars_and_points():
+    rng = np.random.default_rng(7)
+    n = 600
+    S = rand_fr_limbs(rng, n)
+    Pts, _ = rand_g1_limbs(rng, n)
+    S[0] = 0
+    S[1] = limb_row(1)
+    S[2] = limb_row(o.R - 1)
+    S[3] = limb_row(2)
+    S[4] = limb_row((1 << 253) + 12345)
+    Pts[5] = 0                       # infinity input (Python None)
+    Pts[7] = Pts[6]                  # duplicate point, different scalars
+    Pts[9] = Pts[8]
+    S[9] = S[8]                      # duplicate (scalar, point) pair -> doubling inside a bucket
+    neg = co.g1_to_arr([o.g1_neg(co.g1_from_arr(Pts[10])[0])])[0]
+    Pts[11] = neg
+    S[11] = S[10]                    # P and -P with equal scalars cancel
+    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_arr(S, Pts))
+
+
+def test_g1_msm_infinity_results():
+    rng = np.random.default_rng(8)
+    Pts, _ = rand_g1_limbs(rng, 10)
+    Z = np.zeros((10, 4), dtype=np.uint64)
+    assert not msm_g1(Z, Pts).any()                                  # all-zero scalars -> None
+    S = rand_fr_limbs(rng, 10)
+    assert not msm_g1(S, np.zeros((10, 8), dtype=np.uint64)).any()   # all-infinity points -> None
+    # s*P + (r-s)*P = infinity
+    s = int.from_bytes(rng.bytes(31), "little")
+    S2 = co.to_limbs([s, o.R - s])
+    P2 = np.stack([Pts[0], Pts[0]])
+    assert not msm_g1(S2, P2).any()
+    out = np.ones(8, dtype=np.uint64)
+    inf = ctypes.c_int(0)
+    assert _lib.load().zk_msm_g1(None, None, 0, _lib.ptr(out), ctypes.byref(inf)) == 0   # n = 0
+    assert inf.value == 1 and not out.any()
+
+
+def test_g1_msm_rejects_non_canonical_scalar():
+    rng = np.random.default_rng(9)
+    Pts, _ = rand_g1_limbs(rng, 4)
+    S = rand_fr_limbs(rng, 4)
+    S[2] = limb_row(o.R)  # == r: not canonical
+    out = np.zeros(8, dtype=np.uint64)
+    assert _lib.load().zk_msm_g1(_lib.ptr(S), _lib.ptr(Pts), 4, _lib.ptr(out), None) == _lib.ZK_ERR_INVALID
+
+
+@pytest.mark.parametrize("pattern", ["all_equal", "witness_like", "tiny_values"])
+def test_g1_msm_skewed_scalars(pattern):
+    """Witness-like inputs put many points into very few buckets (SURVEY.md section 7 'hard parts')."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    Pts, _ = rand_g1_limbs(rng, n)
+    if pattern == "all_equal":
+        S = np.tile(rand_fr_limbs(rng, 1), (n, 1))
+    elif pattern == "witness_like":
+        S = rand_fr_limbs(rng, n)
+        pick = rng.integers(0, 4, size=n)
+        S[pick == 0] = 0
+        S[pick == 1] = limb_row(1)
+    else:
+        S = co.to_limbs([int(v) for v in rng.integers(0, 40, size=n)])
+    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_arr(S, Pts))
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 513, 700])
+def test_g2_msm_bit_exact_vs_oracle(n):
+    rng = np.random.default_rng(2000 + n)
+    S = rand_fr_limbs(rng, n)
+    Pts, _ = rand_g2_limbs(rng, n)
+    if n > 4:
+        S[0] = 0
+        S[1] = limb_row(o.R - 1)
+        Pts[2] = 0
+        Pts[4] = Pts[3]
+    assert np.array_equal(msm_g2(S, Pts), co.g2_msm_arr(S, Pts))
+
+
+def test_device_plan_reuse_partials_and_profile():
+    import torch
+    rng = np.random.default_rng(12)
+    n = 20000
+    S = rand_fr_limbs(rng, n)
+    Pts, _ = rand_g1_limbs(rng, n)
+    dS = torch.from_numpy(S.view(np.int64)).cuda()
+    dP = torch.from_numpy(Pts.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    plan.set_profiling(True)
+    full, inf = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), n, st)
+    assert not inf and np.array_equal(full, co.g1_msm_arr(S, Pts))
+    ms = plan.stage_ms()
+    assert len(ms) == 4 and all(v > 0 for v in ms)
+    # the same plan serves smaller MSMs (other window widths) and sub-ranges
+    for m in (300, 5000):
+        got, _ = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), m, st)
+        assert np.array_equal(got, co.g1_msm_arr(S[:m], Pts[:m]))
+    # chunk-additivity = the multi-GPU recombination: fold(partial(lo half), partial(hi half)) == full
+    h = n // 2
+    p0 = plan.run_partial(dS.data_ptr(), dP.data_ptr(), h, st)
+    p1 = plan.run_partial(dS.data_ptr() + h * 32, dP.data_ptr() + h * 64, n - h, st)
+    got = fold_partials(_lib.GROUP_G1, np.stack([p0, p1]))
+    assert co.g1_to_arr([(int(got[0]), int(got[1]))])[0].tolist() == full.tolist()
+
+
+def test_g1_msm_2pow16_bit_exact():
+    rng = np.random.default_rng(13)
+    n = 1 << 16
+    S = rand_fr_limbs(rng, n)
+    Pts, _ = rand_g1_limbs(rng, n)
+    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_arr(S, Pts))
+
+
+def test_g1_msm_2pow20_closed_form_and_linearity():
+    """BASELINE.json configs[1] size.  P_i = k_i*G1, so MSM(s, P) = (sum s_i k_i mod r) * G1; also
+    MSM(2s) = 2*MSM(s) and MSM(s) + MSM(t) = MSM(s + t)."""
+    from bench import random_scalars
+    rng = np.random.default_rng(14)
+    n = 1 << 20
+    S, T, K = random_scalars(rng, n), random_scalars(rng, n), random_scalars(rng, n)
+    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+    Pts = np.zeros((n, 8), dtype=np.uint64)
+    _lib.check(_lib.load().zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(K), n, _lib.ptr(Pts)))
+    # spot-check the generated bases against the oracle
+    idx = [0, 1, 12345, n - 1]
+    assert np.array_equal(Pts[idx], co.g1_fixed_base_arr(o.G1, K[idx]))
+    ms = msm_g1(S, Pts)
+    assert co.g1_from_arr(ms)[0] == co.g1_mul(o.G1, co.fr_dot_arr(S, K))
+    mt = msm_g1(T, Pts)
+    assert co.g1_from_arr(mt)[0] == co.g1_mul(o.G1, co.fr_dot_arr(T, K))
+    st_ints = [(a + b) % o.R for a, b in zip(co.from_limbs(S[:4096]), co.from_limbs(T[:4096]))]
+    # linearity on a 4096-point prefix (full-size scalar addition in Python would dominate the test time)
+    a = msm_g1(np.ascontiguousarray(S[:4096]), np.ascontiguousarray(Pts[:4096]))
+    b = msm_g1(np.ascontiguousarray(T[:4096]), np.ascontiguousarray(Pts[:4096]))
+    c = msm_g1(co.to_limbs(st_ints), np.ascontiguousarray(Pts[:4096]))
+    assert co.g1_from_arr(c)[0] == co.g1_add(co.g1_from_arr(a)[0], co.g1_from_arr(b)[0])
+    dbl = co.to_limbs([2 * v % o.R for v in co.from_limbs(S[:4096])])
+    d = msm_g1(dbl, np.ascontiguousarray(Pts[:4096]))
+    assert co.g1_from_arr(d)[0] == co.g1_add(co.g1_from_arr(a)[0], co.g1_from_arr(a)[0])

@@ -1,0 +1,100 @@
+"""CPU tests of the exact field/curve code the HIP kernels run (csrc/field.h, csrc/curve.h compiled
+for the host in tests/hostmath) against the oracle: limb arithmetic, Montgomery conversions, XYZZ
+formulas and every exceptional case (P+P, P+(-P), infinity operands)."""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import c_oracle as co
+import py_ref as o
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hm():
+    d = os.path.join(HERE, "hostmath")
+    subprocess.check_call(["make", "-s", "-C", d])
+    return ctypes.CDLL(os.path.join(d, "libhostmath.so"))
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def fop(hm, which, op, a, b=0):
+    A, B, O = co.to_limbs([a]), co.to_limbs([b]), np.zeros(4, dtype=np.uint64)
+    hm.hm_field_op(which, op, P(A), P(B), P(O))
+    return co.from_limbs(O)[0]
+
+
+def test_field_ops(hm):
+    rnd = random.Random(2)
+    for which, m in ((0, o.P), (1, o.R)):
+        vals = [0, 1, 2, m - 1, m - 2, (1 << 253), (1 << 253) - 1] + [rnd.randrange(m) for _ in range(300)]
+        for i in range(len(vals) - 1):
+            a, b = vals[i], vals[i + 1]
+            assert fop(hm, which, 0, a, b) == (a + b) % m
+            assert fop(hm, which, 1, a, b) == (a - b) % m
+            assert fop(hm, which, 2, a, b) == a * b % m
+            assert fop(hm, which, 4, a) == (-a) % m
+            assert fop(hm, which, 5, a) == a * a % m
+        for a in vals[1:12]:
+            assert fop(hm, which, 3, a) == pow(a, -1, m)
+
+
+def g1mul(hm, p, k):
+    A, K, O = co.g1_to_arr([p]), co.to_limbs([k]), np.zeros(8, dtype=np.uint64)
+    hm.hm_g1_mul(P(A), P(K), P(O))
+    return co.g1_from_arr(O)[0]
+
+
+def g2mul(hm, p, k):
+    A, K, O = co.g2_to_arr([p]), co.to_limbs([k]), np.zeros(16, dtype=np.uint64)
+    hm.hm_g2_mul(P(A), P(K), P(O))
+    return co.g2_from_arr(O)[0]
+
+
+def g1add(hm, mode, p, q, k1=1, k2=1):
+    A, B, K1, K2, O = co.g1_to_arr([p]), co.g1_to_arr([q]), co.to_limbs([k1]), co.to_limbs([k2]), np.zeros(8, dtype=np.uint64)
+    hm.hm_g1_add(mode, P(A), P(B), P(K1), P(K2), P(O))
+    return co.g1_from_arr(O)[0]
+
+
+def g2add(hm, mode, p, q, k1=1, k2=1):
+    A, B, K1, K2, O = co.g2_to_arr([p]), co.g2_to_arr([q]), co.to_limbs([k1]), co.to_limbs([k2]), np.zeros(16, dtype=np.uint64)
+    hm.hm_g2_add(mode, P(A), P(B), P(K1), P(K2), P(O))
+    return co.g2_from_arr(O)[0]
+
+
+def test_scalar_mul(hm):
+    rnd = random.Random(3)
+    for k in [0, 1, 2, 3, o.R - 1, o.R] + [rnd.randrange(o.R) for _ in range(6)]:
+        assert g1mul(hm, o.G1, k) == co.g1_mul(o.G1, k)
+        assert g2mul(hm, o.G2, k) == co.g2_mul(o.G2, k)
+    assert g1mul(hm, None, 5) is None
+
+
+def test_add_exceptional_cases(hm):
+    A, B = o.g1_multiply(o.G1, 123), o.g1_multiply(o.G1, 456)
+    for p, q in [(A, B), (A, A), (A, o.g1_neg(A)), (None, A), (A, None), (None, None)]:
+        assert g1add(hm, 0, p, q) == o.g1_add(p, q)
+    for k1, k2 in [(5, 7), (5, 5), (5, o.R - 5), (0, 5), (5, 0), (0, 0)]:
+        assert g1add(hm, 1, A, A, k1, k2) == o.g1_multiply(A, (k1 + k2) % o.R)
+    A2, B2 = o.g2_multiply(o.G2, 123), o.g2_multiply(o.G2, 456)
+    for p, q in [(A2, B2), (A2, A2), (A2, o.g2_neg(A2)), (None, A2), (A2, None)]:
+        assert g2add(hm, 0, p, q) == o.g2_add(p, q)
+    for k1, k2 in [(5, 7), (5, 5), (5, o.R - 5), (0, 5), (5, 0)]:
+        assert g2add(hm, 1, A2, A2, k1, k2) == o.g2_multiply(A2, (k1 + k2) % o.R)
+
+
+def test_small_mul(hm):
+    A = o.g1_multiply(o.G1, 99)
+    for k in (0, 1, 2, 255, 32768, 65535):
+        Ai, O = co.g1_to_arr([A]), np.zeros(8, dtype=np.uint64)
+        hm.hm_g1_small_mul(P(Ai), ctypes.c_uint32(k), P(O))
+        assert co.g1_from_arr(O)[0] == o.g1_multiply(A, k)

@@ -1,0 +1,215 @@
+"""CPU tests: the oracle (oracle/py_ref.py + oracle/bn254_oracle.c) against the committed golden
+fixtures, the reference's surviving known-answers, and the relational identities the reference's
+own tests assert.  These pin the checker before it is trusted by the GPU parity tests."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import c_oracle as co
+import py_ref as o
+
+P, R = o.P, o.R
+
+
+def _g1(v):
+    return None if v is None else (int(v[0]), int(v[1]))
+
+
+def _g2(v):
+    return None if v is None else ((int(v[0][0]), int(v[0][1])), (int(v[1][0]), int(v[1][1])))
+
+
+@pytest.fixture(scope="module")
+def toy(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "toy_groth16.json")))
+
+
+@pytest.fixture(scope="module")
+def kzg(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "kzg_seed42.json")))
+
+
+@pytest.fixture(scope="module")
+def ntt(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "ntt_small.json")))
+
+
+# ---------------------------------------------------------------- constants / known answers
+def test_constants_appendix_a():
+    assert o.g1_is_on_curve(o.G1) and o.g2_is_on_curve(o.G2)
+    assert o.g1_multiply(o.G1, R) is None and o.g2_multiply(o.G2, R) is None
+    assert (R - 1) % (1 << 28) == 0 and ((R - 1) >> 28) % 2 == 1  # 2-adicity 28 (zkp/plonk/field.py:171)
+    assert pow(5, (R - 1) // 2, R) == R - 1                       # 5 is a non-residue
+    assert o.get_root_of_unity(4) == 21888242871839275217838484774961031246007050428528088939761107053157389710902
+    assert o.srs_tau(42) == 8365577799539384663899794442022354891237484320765090705979616311134436098119
+
+
+def test_reference_comment_kats():
+    """F_r known-answers that survive in zkp/groth16/backend.py:355,363 (with pub = [0, 1])."""
+    d = o.toy_groth16()
+    assert d["A"] * d["B"] % R == 21888242871839275222246405745257275088548364400416033032405666501928354297837
+    assert d["VAL"][0] == 17858330771234736835653075572704017103548042849750409710240473560856989375368
+    assert d["rem"] == [0, 0, 0, 0]
+    assert d["Hx"][:3] == [(-528) % R, 2456, (-496) % R] and d["Hx"][3:] == [0, 0, 0, 0]
+
+
+def test_val5_with_pub_0_5():
+    """VAL[5] of zkp/groth16/backend.py:364 is quoted for pub = [0, 5]."""
+    t = o.TOY
+    Ax = [[v % R for v in row] for row in t["Ap"]]
+    Bx = [[v % R for v in row] for row in t["Bp"]]
+    Cx = [[v % R for v in row] for row in t["Cp"]]
+    x = t["x_val"]
+    Axv, Bxv, Cxv = ([o.eval_poly(p, x) for p in M] for M in (Ax, Bx, Cx))
+    _, VAL = o.sigma13(6, t["alpha"], t["beta"], t["gamma"], Axv, Bxv, Cxv, [0, 5])
+    assert VAL[5] == 3057428741774924004453806255227791707084339019243572619533744442206670609805
+
+
+# ---------------------------------------------------------------- golden fixtures
+def test_toy_groth16_golden(toy):
+    d = o.toy_groth16()
+    assert [str(v) for v in d["Hx"]] == toy["Hx"]
+    assert _g1(toy["proof_A"]) == d["proof_A"]
+    assert _g2(toy["proof_B"]) == d["proof_B"]
+    assert _g1(toy["proof_C"]) == d["proof_C"]
+    assert [_g1(p) for p in toy["sigma1_2"]] == d["s12"]
+    assert [_g1(p) for p in toy["sigma1_4"]] == d["s14"]
+    assert [_g2(p) for p in toy["sigma2_2"]] == d["s22"]
+    # completeness identity of zkp/groth16/test.py:303-333
+    A, B, C = int(toy["A"]), int(toy["B"]), int(toy["C"])
+    t = o.TOY
+    pubsum = sum(t["R"][i] * int(toy["VAL"][i]) for i in t["pub"])
+    assert A * B % R == (t["alpha"] * t["beta"] + t["gamma"] * pubsum + C * t["delta"]) % R
+    assert d["proof_A"] == co.g1_mul(o.G1, A) and d["proof_C"] == co.g1_mul(o.G1, C)
+    assert d["proof_B"] == co.g2_mul(o.G2, B)
+
+
+def test_setup_relations(toy):
+    """tests/groth16/test_setup.py:15-28,37-40: sigma elements are the stated multiples of G."""
+    t = o.TOY
+    s11 = [_g1(p) for p in toy["sigma1_1"]]
+    assert s11 == [o.g1_multiply(o.G1, t["alpha"]), o.g1_multiply(o.G1, t["beta"]), o.g1_multiply(o.G1, t["delta"])]
+    s12 = [_g1(p) for p in toy["sigma1_2"]]
+    assert s12[0] == o.G1 and s12[1] == o.g1_multiply(o.G1, t["x_val"])
+    s13 = [_g1(p) for p in toy["sigma1_3"]]
+    assert s13[2] == (0, 0) and s13[0] == o.g1_multiply(o.G1, int(toy["VAL"][0]))
+    s21 = [_g2(p) for p in toy["sigma2_1"]]
+    assert s21[1] == o.g2_multiply(o.G2, t["gamma"])
+
+
+def test_kzg_golden(kzg):
+    g1p, g2p = o.srs_generate(8, 42)
+    assert [_g1(p) for p in kzg["g1_powers"]] == g1p
+    assert [_g2(p) for p in kzg["g2_powers"]] == g2p
+    assert _g1(kzg["two_G1"]) == (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+                                  9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    for name, c in kzg["commits"].items():
+        coeffs = [int(v) for v in c["coeffs"]]
+        assert o.kzg_commit(coeffs, g1p) == _g1(c["commitment"]), name
+        # C oracle agrees (msm over the same bases)
+        got = co.g1_from_arr(co.g1_msm_arr(co.to_limbs(coeffs), co.g1_to_arr(g1p[:len(coeffs)])))[0]
+        assert got == _g1(c["commitment"]), name
+
+
+def test_kzg_relations(kzg):
+    """tests/plonk/test_crypto.py:113-191: constant, linear, zero, degree overflow, linearity, scaling."""
+    g1p = [_g1(p) for p in kzg["g1_powers"]]
+    assert o.kzg_commit([7], g1p) == o.g1_multiply(o.G1, 7)
+    assert o.kzg_commit([3, 5], g1p) == o.g1_add(o.g1_multiply(g1p[0], 3), o.g1_multiply(g1p[1], 5))
+    assert o.kzg_commit([0], g1p) is None
+    with pytest.raises(ValueError):
+        o.kzg_commit([1] * 10, g1p)
+    p, q = [1, 2], [3, 4]
+    assert o.kzg_commit([4, 6], g1p) == o.g1_add(o.kzg_commit(p, g1p), o.kzg_commit(q, g1p))
+    assert o.kzg_commit([10, 15], g1p) == o.g1_multiply(o.kzg_commit([2, 3], g1p), 5)
+
+
+def test_ntt_golden(ntt):
+    assert int(ntt["omega_4"]) == o.get_root_of_unity(4)
+    for name, c in ntt["cases"].items():
+        coeffs = [int(v) for v in c["coeffs"]]
+        w = int(c["omega"])
+        exp = [int(v) for v in c["fft"]]
+        assert o.fft(coeffs, w) == exp, name
+        assert co.from_limbs(co.ntt_arr(co.to_limbs(coeffs), w)) == exp, name
+        assert co.from_limbs(co.ntt_arr(co.to_limbs(exp), w, inverse=True)) == [v % R for v in coeffs], name
+        assert o.coset_fft(coeffs, w) == [int(v) for v in c["coset_fft_k5"]], name
+        assert o.ifft(coeffs, w) == [int(v) for v in c["ifft_of_coeffs"]], name
+
+
+def test_fft_relations():
+    """tests/plonk/test_foundation.py:486-540, 724-760."""
+    assert o.fft([7], 1) == [7] and o.ifft([7], 1) == [7]
+    n = 8
+    w = o.get_root_of_unity(n)
+    coeffs = list(range(n))
+    ev = o.fft(coeffs, w)
+    assert ev[0] == sum(coeffs) % R
+    assert all(ev[i] == o.horner(coeffs, pow(w, i, R)) for i in range(n))
+    orig = [i * 3 + 1 for i in range(n)]
+    assert o.ifft(o.fft(orig, w), w) == orig and o.fft(o.ifft(orig, w), w) == orig
+    assert o.coset_ifft(o.coset_fft(orig, w), w) == orig
+    with pytest.raises(ValueError):
+        o.get_root_of_unity(3)
+    with pytest.raises(ValueError):
+        o.get_root_of_unity(1 << 29)
+
+
+# ---------------------------------------------------------------- C oracle vs Python oracle
+def test_c_oracle_field_and_group():
+    rnd = random.Random(5)
+    for m, which in ((P, 0), (R, 1)):
+        for _ in range(50):
+            a, b = rnd.randrange(m), rnd.randrange(m)
+            assert co.field_op(which, 0, a, b) == (a + b) % m
+            assert co.field_op(which, 1, a, b) == (a - b) % m
+            assert co.field_op(which, 2, a, b) == a * b % m
+        assert co.field_op(which, 3, 12345) == pow(12345, -1, m)
+    for k in (0, 1, 2, R - 1, R, rnd.randrange(R)):
+        assert co.g1_mul(o.G1, k) == o.g1_multiply(o.G1, k)
+        assert co.g2_mul(o.G2, k) == o.g2_multiply(o.G2, k)
+    A, B = o.g1_multiply(o.G1, 123), o.g1_multiply(o.G1, 456)
+    for p, q in ((A, B), (A, A), (A, o.g1_neg(A)), (None, A), (A, None), (None, None)):
+        assert co.g1_add(p, q) == o.g1_add(p, q)
+    A2, B2 = o.g2_multiply(o.G2, 123), o.g2_multiply(o.G2, 456)
+    for p, q in ((A2, B2), (A2, A2), (A2, o.g2_neg(A2)), (None, A2)):
+        assert co.g2_add(p, q) == o.g2_add(p, q)
+
+
+def test_c_oracle_msm_vs_python():
+    rnd = random.Random(6)
+    n = 24
+    sc = [rnd.randrange(R) for _ in range(n)]
+    sc[3], sc[4], sc[5] = 0, 1, R - 1
+    pts = [o.g1_multiply(o.G1, rnd.randrange(1, R)) for _ in range(n)]
+    pts[7] = None
+    pts[9] = pts[8]                 # duplicate point
+    pts[11] = o.g1_neg(pts[10])     # P and -P
+    sc[11] = sc[10]
+    assert co.g1_from_arr(co.g1_msm_arr(co.to_limbs(sc), co.g1_to_arr(pts)))[0] == o.msm_naive(sc, pts)
+    pts2 = [o.g2_multiply(o.G2, rnd.randrange(1, R)) for _ in range(6)]
+    assert co.g2_from_arr(co.g2_msm_arr(co.to_limbs(sc[:6]), co.g2_to_arr(pts2)))[0] == o.msm_naive(sc[:6], pts2)
+    # closed form: points k_i*G  ->  (sum s_i k_i) * G
+    ks = [rnd.randrange(R) for _ in range(n)]
+    P_arr = co.g1_fixed_base_arr(o.G1, co.to_limbs(ks))
+    dot = co.fr_dot_arr(co.to_limbs(sc), co.to_limbs(ks))
+    assert dot == sum(a * b for a, b in zip(sc, ks)) % R
+    assert co.g1_from_arr(co.g1_msm_arr(co.to_limbs(sc), P_arr))[0] == o.g1_multiply(o.G1, dot)
+
+
+def test_c_oracle_ntt_sizes():
+    rnd = random.Random(7)
+    for L in range(0, 9):
+        n = 1 << L
+        x = [rnd.randrange(R) for _ in range(n)]
+        w = o.get_root_of_unity(n)
+        assert co.from_limbs(co.ntt_arr(co.to_limbs(x), w)) == o.fft(x, w)
+    x = co.to_limbs([rnd.randrange(R) for _ in range(1 << 12)])
+    w = o.get_root_of_unity(1 << 12)
+    y = co.ntt_arr(x, w)
+    assert np.array_equal(co.ntt_arr(y, w, inverse=True), x)
+    for i in (0, 1, 77, 4095):
+        assert co.from_limbs(y[i:i + 1])[0] == co.fr_horner_arr(x, pow(w, i, R))
