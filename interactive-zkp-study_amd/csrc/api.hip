@@ -38,37 +38,26 @@ static bool scalars_canonical(const uint64_t *s, size_t n) {
 }
 
 // ------------------------------------------------------------------ batch group-op kernels
-template <class F> __device__ __forceinline__ Affine<F> load_affine_canonical(const uint32_t *p);
-template <> __device__ __forceinline__ Affine<Fp> load_affine_canonical<Fp>(const uint32_t *p) {
-    Affine<Fp> a;
-    for (int i = 0; i < 8; i++) { a.x.l[i] = p[i]; a.y.l[i] = p[8 + i]; }
-    const bool inf = a.is_inf();
-    a.x = fe_to_mont(a.x); a.y = fe_to_mont(a.y);
-    return inf ? Affine<Fp>::inf() : a;
+template <class F> __device__ __forceinline__ Affine<F> load_affine_canonical(const uint32_t *p) {
+    constexpr int NW = F::CANON_WORDS;
+    uint32_t w[2 * NW];
+    for (int i = 0; i < 2 * NW; i++) w[i] = p[i];
+    const F x = fe_load_canonical(w, (F *)nullptr), y = fe_load_canonical(w + NW, (F *)nullptr);
+    if (x.is_zero() && y.is_zero()) return Affine<F>::inf();
+    return Affine<F>{fe_to_mont(x), fe_to_mont(y)};
 }
-template <> __device__ __forceinline__ Affine<Fp2> load_affine_canonical<Fp2>(const uint32_t *p) {
-    Affine<Fp2> a;
-    for (int i = 0; i < 8; i++) { a.x.c0.l[i] = p[i]; a.x.c1.l[i] = p[8 + i]; a.y.c0.l[i] = p[16 + i]; a.y.c1.l[i] = p[24 + i]; }
-    const bool inf = a.is_inf();
-    a.x = fe_to_mont(a.x); a.y = fe_to_mont(a.y);
-    return inf ? Affine<Fp2>::inf() : a;
-}
-__device__ __forceinline__ void store_fe_canonical(uint32_t *o, const Fp &a) {
-    Fp c = fe_from_mont(a);
-    for (int i = 0; i < 8; i++) o[i] = c.l[i];
-}
-__device__ __forceinline__ void store_affine_canonical(uint32_t *o, const Affine<Fp> &a) {
-    store_fe_canonical(o, a.x); store_fe_canonical(o + 8, a.y);
-}
-__device__ __forceinline__ void store_affine_canonical(uint32_t *o, const Affine<Fp2> &a) {
-    store_fe_canonical(o, a.x.c0); store_fe_canonical(o + 8, a.x.c1);
-    store_fe_canonical(o + 16, a.y.c0); store_fe_canonical(o + 24, a.y.c1);
+template <class F> __device__ __forceinline__ void store_affine_canonical(uint32_t *o, const Affine<F> &a) {
+    constexpr int NW = F::CANON_WORDS;
+    uint32_t w[2 * NW];
+    fe_store_canonical(w, fe_from_mont(a.x));
+    fe_store_canonical(w + NW, fe_from_mont(a.y));
+    for (int i = 0; i < 2 * NW; i++) o[i] = w[i];
 }
 
 // op 0: out[i] = p[i] + q[i];  op 1: out[i] = k[i] * p[i];  op 2: out[i] = k[i] * p[0] (fixed base)
 template <class F>
 __global__ __launch_bounds__(64) void group_op_kernel(int op, const uint32_t *p, const uint32_t *q, uint32_t *out, uint32_t n) {
-    constexpr int PW = sizeof(Affine<F>) / 4;
+    constexpr int PW = 2 * F::CANON_WORDS;
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     Xyzz<F> r;
@@ -85,7 +74,7 @@ __global__ __launch_bounds__(64) void group_op_kernel(int op, const uint32_t *p,
 }
 
 template <class F> static int group_op_host(int op, const uint64_t *p, const uint64_t *q, size_t n, uint64_t *out) {
-    constexpr size_t PB = sizeof(Affine<F>);
+    constexpr size_t PB = 8 * F::CANON_WORDS;  // bytes of one canonical affine point
     if (n == 0) return ZK_OK;
     const size_t p_bytes = (op == 2 ? 1 : n) * PB, q_bytes = n * (op == 0 ? PB : 32);
     DevBuf dp(p_bytes), dq(q_bytes), dout(n * PB);
@@ -99,7 +88,7 @@ template <class F> static int group_op_host(int op, const uint64_t *p, const uin
 }
 
 template <class F> static int msm_host(int group, const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t *out_xy, int *out_is_inf) {
-    constexpr size_t PB = sizeof(Affine<F>);
+    constexpr size_t PB = 8 * F::CANON_WORDS;
     if (n == 0) {
         memset(out_xy, 0, PB);
         if (out_is_inf) *out_is_inf = 1;

@@ -26,21 +26,23 @@ template <class F> struct Xyzz {
     }
 };
 
-template <class F> ZK_HD Affine<F> affine_neg(const Affine<F> &p) { return Affine<F>{p.x, fe_neg(p.y)}; }
-template <class F> ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F> &p) { return Xyzz<F>{p.x, fe_neg(p.y), p.zz, p.zzz}; }
+// Value bounds (multiples of the modulus m) maintained by every routine below; they are what the
+// K arguments of fe_sub<K> / fe_neg<K> encode (field.h contracts; mul outputs are < 2m):
+//   affine coordinates < 2m;   XYZZ:  X < 8m,  Y < 4m,  ZZ < 2m,  ZZZ < 2m.
+template <class F> ZK_HD Affine<F> affine_neg(const Affine<F> &p) { return Affine<F>{p.x, fe_neg<2>(p.y)}; }
+template <class F> ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F> &p) { return Xyzz<F>{p.x, fe_neg<4>(p.y), p.zz, p.zzz}; }
 
 // 2*P for affine P (mdbl-2008-s-1).
 template <class F> ZK_HD Xyzz<F> xyzz_dbl_affine(const Affine<F> &p) {
     if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
-    F u = fe_dbl(p.y);
+    F u = fe_dbl(p.y);                       // < 4m
     F v = fe_sqr(u);
     F w = fe_mul(u, v);
     F s = fe_mul(p.x, v);
-    F x2 = fe_sqr(p.x);
-    F m = fe_add(fe_dbl(x2), x2);
+    F m = fe_triple(fe_sqr(p.x));            // < 6m
     Xyzz<F> r;
-    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
-    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, p.y));
+    r.x = fe_sub<4>(fe_sqr(m), fe_dbl(s));   // < 6m
+    r.y = fe_sub<2>(fe_mul(m, fe_sub<6>(s, r.x)), fe_mul(w, p.y));  // < 4m
     r.zz = v;
     r.zzz = w;
     return r;
@@ -49,15 +51,14 @@ template <class F> ZK_HD Xyzz<F> xyzz_dbl_affine(const Affine<F> &p) {
 // 2*P (dbl-2008-s-1).
 template <class F> ZK_HD Xyzz<F> xyzz_dbl(const Xyzz<F> &p) {
     if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
-    F u = fe_dbl(p.y);
+    F u = fe_dbl(p.y);                       // < 8m
     F v = fe_sqr(u);
     F w = fe_mul(u, v);
     F s = fe_mul(p.x, v);
-    F x2 = fe_sqr(p.x);
-    F m = fe_add(fe_dbl(x2), x2);
+    F m = fe_triple(fe_sqr(p.x));            // < 6m
     Xyzz<F> r;
-    r.x = fe_sub(fe_sqr(m), fe_dbl(s));
-    r.y = fe_sub(fe_mul(m, fe_sub(s, r.x)), fe_mul(w, p.y));
+    r.x = fe_sub<4>(fe_sqr(m), fe_dbl(s));   // < 6m
+    r.y = fe_sub<2>(fe_mul(m, fe_sub<6>(s, r.x)), fe_mul(w, p.y));  // < 4m
     r.zz = fe_mul(v, p.zz);
     r.zzz = fe_mul(w, p.zzz);
     return r;
@@ -72,8 +73,8 @@ template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) 
     }
     F u2 = fe_mul(q.x, acc.zz);
     F s2 = fe_mul(q.y, acc.zzz);
-    F p = fe_sub(u2, acc.x);
-    F r = fe_sub(s2, acc.y);
+    F p = fe_sub<8>(u2, acc.x);              // < 10m
+    F r = fe_sub<4>(s2, acc.y);              // < 6m
     if (p.is_zero()) {
         if (r.is_zero())
             acc = xyzz_dbl_affine(q);
@@ -81,11 +82,11 @@ template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) 
             acc = Xyzz<F>::inf();
         return;
     }
-    F pp = fe_sqr(p);
+    F pp = fe_sqr(p);                        // 10*10 < 169
     F ppp = fe_mul(p, pp);
-    F qq = fe_mul(acc.x, pp);
-    F x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(qq));
-    F y3 = fe_sub(fe_mul(r, fe_sub(qq, x3)), fe_mul(acc.y, ppp));
+    F qq = fe_mul(acc.x, pp);                // 8*2
+    F x3 = fe_sub<6>(fe_sqr(r), fe_add(ppp, fe_dbl(qq)));           // < 8m
+    F y3 = fe_sub<2>(fe_mul(r, fe_sub<8>(qq, x3)), fe_mul(acc.y, ppp));  // 6*10 < 169;  < 4m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(acc.zz, pp);
@@ -99,12 +100,12 @@ template <class F> ZK_HD void xyzz_add(Xyzz<F> &acc, const Xyzz<F> &q) {
         acc = q;
         return;
     }
-    F u1 = fe_mul(acc.x, q.zz);
+    F u1 = fe_mul(acc.x, q.zz);              // 8*2
     F u2 = fe_mul(q.x, acc.zz);
     F s1 = fe_mul(acc.y, q.zzz);
     F s2 = fe_mul(q.y, acc.zzz);
-    F p = fe_sub(u2, u1);
-    F r = fe_sub(s2, s1);
+    F p = fe_sub<2>(u2, u1);                 // < 4m
+    F r = fe_sub<2>(s2, s1);                 // < 4m
     if (p.is_zero()) {
         if (r.is_zero())
             acc = xyzz_dbl(acc);
@@ -115,8 +116,8 @@ template <class F> ZK_HD void xyzz_add(Xyzz<F> &acc, const Xyzz<F> &q) {
     F pp = fe_sqr(p);
     F ppp = fe_mul(p, pp);
     F qq = fe_mul(u1, pp);
-    F x3 = fe_sub(fe_sub(fe_sqr(r), ppp), fe_dbl(qq));
-    F y3 = fe_sub(fe_mul(r, fe_sub(qq, x3)), fe_mul(s1, ppp));
+    F x3 = fe_sub<6>(fe_sqr(r), fe_add(ppp, fe_dbl(qq)));           // < 8m
+    F y3 = fe_sub<2>(fe_mul(r, fe_sub<8>(qq, x3)), fe_mul(s1, ppp));     // 4*10;  < 4m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);

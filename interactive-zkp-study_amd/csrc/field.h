@@ -1,6 +1,23 @@
-// field.h -- 254-bit prime-field arithmetic for BN254 (F_p and F_r), Montgomery form,
-// radix 2^256, 8 x 32-bit little-endian limbs.  One definition for host and gfx950 device
-// code: on the device every limb is a VGPR and the inner products lower to v_mad_u64_u32.
+// field.h -- 254-bit prime-field arithmetic for BN254 (F_p and F_r) on gfx950.
+//
+// Representation: 9 limbs x 29 bits (reduced radix), Montgomery radix 2^261.  On CDNA4 the
+// 32x32+64 multiply-add v_mad_u64_u32 issues at nearly the rate of a 64-bit add (measured
+// ~5 vs ~4.4 cycles per wave-instruction, tools/ubench.hip), so the cheapest modular product is
+// the one with the fewest NON-multiply instructions: with 29-bit limbs a whole column of the
+// product (<= 18 terms of < 2^60) accumulates in one 64-bit register pair with no carry
+// handling at all -- 171 multiply-adds plus ~30 shifts/masks per Montgomery product, against
+// 136 multiply-adds plus ~470 carry instructions for saturated 8 x 32-bit limbs.
+//
+// Values are kept "lazy": limbs are normalised to < 2^29 (top limb holds the excess), but the
+// VALUE is only bounded by a small multiple of the modulus (< 16 m); nothing is conditionally
+// subtracted on the hot path.  Contracts (m = modulus, R = 2^261, R/m ~ 169):
+//   fe_mul / fe_sqr   inputs: limbs < 2^30.5 (a sum of two normalised elements may be fed
+//                     unnormalised), values va, vb with va*vb < 169 m^2;  output: normalised,
+//                     value < va*vb/R + m  (< 2m under the contract).
+//   fe_add            value a+b, normalised.         fe_sub_k<K>: a - b + K*m (needs b <= K*m).
+//   fe_wreduce<M>     value < M*m (M <= 16) -> < 2m.  fe_reduce_full: < 16m -> canonical < m.
+// curve.h documents the bound of every intermediate of its formulas against these contracts;
+// tests/hostmath runs the same code on the CPU with ZK_FIELD_DEBUG bound tracking.
 //
 // Replaces (as arithmetic) what the reference gets from py_ecc's FQ / its own FR subclass:
 //   zkp/plonk/field.py:36-51 (FR), zkp/groth16/proving.py:20-21.
@@ -20,194 +37,277 @@ namespace zk {
 struct FpTag {};  // base field   p
 struct FrTag {};  // scalar field r
 
+constexpr int NL = ZK_NLIMBS;          // 9
+constexpr int LB = ZK_LIMB_BITS;       // 29
+constexpr uint32_t LMASK = (1u << LB) - 1u;
+
 template <class Tag> struct FieldConst;
 
-template <> struct FieldConst<FpTag> {
-    static ZK_HD uint32_t mod(int i) {
-        constexpr uint32_t m[8] = ZK_FP_MOD;
-        return m[i];
-    }
-    static ZK_HD uint32_t r1(int i) {
-        constexpr uint32_t m[8] = ZK_FP_R1;
-        return m[i];
-    }
-    static ZK_HD uint32_t r2(int i) {
-        constexpr uint32_t m[8] = ZK_FP_R2;
-        return m[i];
-    }
-    static constexpr uint32_t inv32 = ZK_FP_INV32;
-};
+#define ZK_DEFINE_FIELD_CONST(TAG, PFX)                                                   \
+    template <> struct FieldConst<TAG> {                                                  \
+        static ZK_HD uint32_t mod(int i) {                                                \
+            constexpr uint32_t m[NL] = PFX##_MOD;                                         \
+            return m[i];                                                                  \
+        }                                                                                 \
+        static ZK_HD uint32_t r1(int i) {                                                 \
+            constexpr uint32_t m[NL] = PFX##_R1;                                          \
+            return m[i];                                                                  \
+        }                                                                                 \
+        static ZK_HD uint32_t r2(int i) {                                                 \
+            constexpr uint32_t m[NL] = PFX##_R2;                                          \
+            return m[i];                                                                  \
+        }                                                                                 \
+        static ZK_HD uint32_t kp(int k, int i) { /* limb i of k * modulus, k <= 16 */      \
+            constexpr uint32_t m[17][NL] = PFX##_KP;                                      \
+            return m[k][i];                                                               \
+        }                                                                                 \
+        static constexpr uint32_t inv = PFX##_INV29;                                      \
+    };
+ZK_DEFINE_FIELD_CONST(FpTag, ZK_FP)
+ZK_DEFINE_FIELD_CONST(FrTag, ZK_FR)
 
-template <> struct FieldConst<FrTag> {
-    static ZK_HD uint32_t mod(int i) {
-        constexpr uint32_t m[8] = ZK_FR_MOD;
-        return m[i];
-    }
-    static ZK_HD uint32_t r1(int i) {
-        constexpr uint32_t m[8] = ZK_FR_R1;
-        return m[i];
-    }
-    static ZK_HD uint32_t r2(int i) {
-        constexpr uint32_t m[8] = ZK_FR_R2;
-        return m[i];
-    }
-    static constexpr uint32_t inv32 = ZK_FR_INV32;
-};
-
-// A field element; value semantics, limbs in l[0] (least significant) .. l[7].
-template <class Tag> struct alignas(16) Fe {
-    uint32_t l[8];
+// A field element; value semantics.  l[0..7] < 2^29 when normalised, l[8] holds the rest.
+template <class Tag> struct alignas(4) Fe {
+    uint32_t l[NL];
     typedef FieldConst<Tag> C;
+    static constexpr int CANON_WORDS = 8;  // 32-bit words of the canonical (ABI) encoding
 
     static ZK_HD Fe zero() {
         Fe r;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = 0;
+        for (int i = 0; i < NL; i++) r.l[i] = 0;
         return r;
     }
     static ZK_HD Fe one() {  // Montgomery form of 1
         Fe r;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = C::r1(i);
+        for (int i = 0; i < NL; i++) r.l[i] = C::r1(i);
         return r;
     }
-    ZK_HD bool is_zero() const {
+    ZK_HD bool raw_is_zero() const {  // all limbs zero (exact integer zero)
         uint32_t o = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) o |= l[i];
+        for (int i = 0; i < NL; i++) o |= l[i];
         return o == 0;
     }
-    ZK_HD bool equals(const Fe &b) const {
-        uint32_t o = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o |= (l[i] ^ b.l[i]);
-        return o == 0;
-    }
+    ZK_HD bool is_zero() const;              // value == 0 mod m (any lazy representative)
+    ZK_HD bool equals(const Fe &b) const;    // values equal mod m
 };
 
-// r = a - mod if a >= mod (a < 2*mod)
-template <class Tag> ZK_HD void fe_reduce_once(Fe<Tag> &a) {
+// Carry propagation of limbs that may be >= 2^29 or (as int32) negative; the total value must be
+// non-negative and < 2^(232+31).
+template <class Tag> ZK_HD void fe_normalize(Fe<Tag> &a) {
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        const int32_t t = (int32_t)a.l[i] + c;
+        a.l[i] = (uint32_t)t & LMASK;
+        c = t >> LB;  // arithmetic shift: negative limbs borrow
+    }
+    a.l[NL - 1] = (uint32_t)((int32_t)a.l[NL - 1] + c);
+}
+
+// a - K*m if that is >= 0, else a.  Input normalised.
+template <int K, class Tag> ZK_HD void fe_cond_sub(Fe<Tag> &a) {
     typedef FieldConst<Tag> C;
-    uint32_t t[8];
-    uint64_t borrow = 0;
+    uint32_t d[NL];
+    int32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)a.l[i] - C::mod(i) - borrow;
-        t[i] = (uint32_t)d;
-        borrow = (d >> 63) & 1;
+    for (int i = 0; i < NL - 1; i++) {
+        const int32_t t = (int32_t)a.l[i] - (int32_t)C::kp(K, i) + c;
+        d[i] = (uint32_t)t & LMASK;
+        c = t >> LB;
     }
-    if (!borrow) {
+    const int32_t top = (int32_t)a.l[NL - 1] - (int32_t)C::kp(K, NL - 1) + c;
+    d[NL - 1] = (uint32_t)top;
+    if (top >= 0) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) a.l[i] = t[i];
+        for (int i = 0; i < NL; i++) a.l[i] = d[i];
     }
+}
+
+// value < M*m (M <= 16)  ->  value < 2m
+template <int M, class Tag> ZK_HD void fe_wreduce(Fe<Tag> &a) {
+    if (M > 8) fe_cond_sub<8>(a);
+    if (M > 4) fe_cond_sub<4>(a);
+    if (M > 2) fe_cond_sub<2>(a);
+}
+// value < 16m -> canonical representative < m
+template <class Tag> ZK_HD Fe<Tag> fe_reduce_full(Fe<Tag> a) {
+    fe_normalize(a);
+    fe_cond_sub<8>(a);
+    fe_cond_sub<4>(a);
+    fe_cond_sub<2>(a);
+    fe_cond_sub<1>(a);
+    return a;
+}
+
+template <class Tag> ZK_HD bool Fe<Tag>::is_zero() const {
+    // Quick reject: a multiple of m below 16m must match k*m in its lowest limb for some k.
+    Fe t = *this;
+    fe_normalize(t);
+    bool maybe = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) maybe |= (t.l[0] == C::kp(k, 0));
+    if (!maybe) return false;
+    return fe_reduce_full(t).raw_is_zero();
+}
+template <class Tag> ZK_HD bool Fe<Tag>::equals(const Fe &b) const {
+    const Fe x = fe_reduce_full(*this), y = fe_reduce_full(b);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o |= (x.l[i] ^ y.l[i]);
+    return o == 0;
 }
 
 template <class Tag> ZK_HD Fe<Tag> fe_add(const Fe<Tag> &a, const Fe<Tag> &b) {
     Fe<Tag> r;
-    uint64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.l[i] + b.l[i];
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    fe_reduce_once(r);  // a+b < 2p < 2^255: no carry out of limb 7
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    fe_normalize(r);
     return r;
 }
-
-template <class Tag> ZK_HD Fe<Tag> fe_sub(const Fe<Tag> &a, const Fe<Tag> &b) {
+// limb-wise sum without carry propagation: only as a direct operand of fe_mul / fe_sqr
+template <class Tag> ZK_HD Fe<Tag> fe_add_lazy(const Fe<Tag> &a, const Fe<Tag> &b) {
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// a - b + K*m; requires value(b) <= K*m.  Result normalised, value < value(a) + K*m.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_sub_k(const Fe<Tag> &a, const Fe<Tag> &b) {
     typedef FieldConst<Tag> C;
     Fe<Tag> r;
-    uint64_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)a.l[i] - b.l[i] - borrow;
-        r.l[i] = (uint32_t)d;
-        borrow = (d >> 63) & 1;
-    }
-    uint32_t mask = (uint32_t)0 - (uint32_t)borrow;  // add the modulus back when a < b
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)r.l[i] + (C::mod(i) & mask);
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + C::kp(K, i) - b.l[i];
+    fe_normalize(r);
     return r;
 }
-
-template <class Tag> ZK_HD Fe<Tag> fe_neg(const Fe<Tag> &a) {
-    if (a.is_zero()) return a;
+// K*m - a; requires value(a) <= K*m.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_neg_k(const Fe<Tag> &a) {
     typedef FieldConst<Tag> C;
     Fe<Tag> r;
-    uint64_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)C::mod(i) - a.l[i] - borrow;
-        r.l[i] = (uint32_t)d;
-        borrow = (d >> 63) & 1;
-    }
+    for (int i = 0; i < NL; i++) r.l[i] = C::kp(K, i) - a.l[i];
+    fe_normalize(r);
+    return r;
+}
+template <class Tag> ZK_HD Fe<Tag> fe_dbl(const Fe<Tag> &a) {
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] << 1;
+    fe_normalize(r);
+    return r;
+}
+template <class Tag> ZK_HD Fe<Tag> fe_triple(const Fe<Tag> &a) {
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] * 3u;
+    fe_normalize(r);
     return r;
 }
 
-template <class Tag> ZK_HD Fe<Tag> fe_dbl(const Fe<Tag> &a) { return fe_add(a, a); }
-
-// Montgomery product a*b*2^-256 mod m, CIOS with 32-bit limbs.  The modulus is < 2^254, so
-// the running sum never needs more than 9 limbs and one conditional subtraction finishes.
+// Montgomery product a*b*2^-261 (product scanning; one 64-bit running column accumulator).
 template <class Tag> ZK_HD Fe<Tag> fe_mul(const Fe<Tag> &a, const Fe<Tag> &b) {
     typedef FieldConst<Tag> C;
-    uint32_t t[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t carry = 0;
-        const uint32_t bi = b.l[i];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint64_t s = (uint64_t)a.l[j] * bi + t[j] + carry;
-            t[j] = (uint32_t)s;
-            carry = s >> 32;
-        }
-        uint32_t t8 = t[8] + (uint32_t)carry;
-        const uint32_t m = t[0] * C::inv32;
-        uint64_t s = (uint64_t)m * C::mod(0) + t[0];
-        carry = s >> 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            s = (uint64_t)m * C::mod(j) + t[j] + carry;
-            t[j - 1] = (uint32_t)s;
-            carry = s >> 32;
-        }
-        s = (uint64_t)t8 + carry;
-        t[7] = (uint32_t)s;
-        t[8] = (uint32_t)(s >> 32);
-    }
+    uint32_t q[NL];
     Fe<Tag> r;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = t[i];
-    fe_reduce_once(r);
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        q[k] = ((uint32_t)acc * C::inv) & LMASK;
+        acc += (uint64_t)q[k] * C::mod(0);
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        r.l[k - NL] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    r.l[NL - 1] = (uint32_t)acc;
     return r;
 }
 
-template <class Tag> ZK_HD Fe<Tag> fe_sqr(const Fe<Tag> &a) { return fe_mul(a, a); }
+// Montgomery square: 45 distinct products instead of 81.
+template <class Tag> ZK_HD Fe<Tag> fe_sqr(const Fe<Tag> &a) {
+    typedef FieldConst<Tag> C;
+    uint32_t q[NL], a2[NL];
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        q[k] = ((uint32_t)acc * C::inv) & LMASK;
+        acc += (uint64_t)q[k] * C::mod(0);
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k >> 1] * a.l[k >> 1];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        r.l[k - NL] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    r.l[NL - 1] = (uint32_t)acc;
+    return r;
+}
 
 template <class Tag> ZK_HD Fe<Tag> fe_to_mont(const Fe<Tag> &a) {
     typedef FieldConst<Tag> C;
     Fe<Tag> r2;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r2.l[i] = C::r2(i);
+    for (int i = 0; i < NL; i++) r2.l[i] = C::r2(i);
     return fe_mul(a, r2);
 }
-
 template <class Tag> ZK_HD Fe<Tag> fe_from_mont(const Fe<Tag> &a) {
     Fe<Tag> one;
 #pragma unroll
-    for (int i = 0; i < 8; i++) one.l[i] = (i == 0);
+    for (int i = 0; i < NL; i++) one.l[i] = (i == 0);
     return fe_mul(a, one);
 }
 
-// a^e for a 256-bit exponent given as limbs (square-and-multiply, MSB first).
+// Canonical 256-bit little-endian words (the ABI encoding) <-> normalised limbs.
+template <class Tag> ZK_HD Fe<Tag> fe_from_words(const uint32_t w[8]) {
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int bit = LB * i, word = bit >> 5, sh = bit & 31;
+        uint32_t v = w[word] >> sh;
+        if (sh + LB > 32 && word + 1 < 8) v |= w[word + 1] << (32 - sh);
+        r.l[i] = (i < NL - 1) ? (v & LMASK) : v;
+    }
+    return r;
+}
+// Input must be canonical (< m < 2^254), e.g. the result of fe_reduce_full.
+template <class Tag> ZK_HD void fe_to_words(const Fe<Tag> &a, uint32_t w[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int bit = 32 * j, li = bit / LB, sh = bit - li * LB;  // word j starts inside limb li
+        uint64_t v = (uint64_t)a.l[li] >> sh;
+        if (li + 1 < NL) v |= (uint64_t)a.l[li + 1] << (LB - sh);
+        if (li + 2 < NL && 2 * LB - sh < 32) v |= (uint64_t)a.l[li + 2] << (2 * LB - sh);
+        w[j] = (uint32_t)v;
+    }
+}
+
+// a^e for a 256-bit exponent given as 32-bit words (square-and-multiply, MSB first); a < 2m.
 template <class Tag> ZK_HD Fe<Tag> fe_pow(const Fe<Tag> &a, const uint32_t e[8]) {
     Fe<Tag> r = Fe<Tag>::one();
     for (int i = 7; i >= 0; i--) {
@@ -218,56 +318,97 @@ template <class Tag> ZK_HD Fe<Tag> fe_pow(const Fe<Tag> &a, const uint32_t e[8])
     }
     return r;
 }
-
 // Inverse by Fermat: a^(m-2).  inv(0) = 0.
 template <class Tag> ZK_HD Fe<Tag> fe_inv(const Fe<Tag> &a) {
     typedef FieldConst<Tag> C;
-    uint32_t e[8];
-    uint64_t borrow = 2;
+    Fe<Tag> m;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t d = (uint64_t)C::mod(i) - borrow;
-        e[i] = (uint32_t)d;
-        borrow = (d >> 63) & 1;
-    }
+    for (int i = 0; i < NL; i++) m.l[i] = C::mod(i);
+    m.l[0] -= 2;  // low limb of both moduli is > 2
+    uint32_t e[8];
+    fe_to_words(m, e);
     return fe_pow(a, e);
 }
 
 typedef Fe<FpTag> Fp;
 typedef Fe<FrTag> Fr;
 
+// Generic names used by curve.h (the host epilogue types in host_field.h provide the same set).
+// mul outputs are < 2m, which is what the K arguments in curve.h are derived from.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_sub(const Fe<Tag> &a, const Fe<Tag> &b) { return fe_sub_k<K>(a, b); }
+template <int K, class Tag> ZK_HD Fe<Tag> fe_neg(const Fe<Tag> &a) { return fe_neg_k<K>(a); }
+
 // ---------------------------------------------------------------------------------------
-// F_p^2 = F_p[i]/(i^2+1); element c0 + c1*i.  (py_ecc FQ2, coeffs [c0, c1].)
+// F_p^2 = F_p[i]/(i^2+1); element c0 + c1*i  (py_ecc FQ2, coeffs [c0, c1]).
+// Every F_p^2 result is weakly reduced (< 2p per component) so that the Karatsuba operand sums
+// stay inside fe_mul's contract: (2p + 2p)^2 = 16 p^2 < 169 p^2.
 struct Fp2 {
     Fp c0, c1;
+    static constexpr int CANON_WORDS = 16;
     static ZK_HD Fp2 zero() { return Fp2{Fp::zero(), Fp::zero()}; }
     static ZK_HD Fp2 one() { return Fp2{Fp::one(), Fp::zero()}; }
     ZK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
     ZK_HD bool equals(const Fp2 &b) const { return c0.equals(b.c0) && c1.equals(b.c1); }
 };
 
-ZK_HD Fp2 fe_add(const Fp2 &a, const Fp2 &b) { return Fp2{fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
-ZK_HD Fp2 fe_sub(const Fp2 &a, const Fp2 &b) { return Fp2{fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
-ZK_HD Fp2 fe_neg(const Fp2 &a) { return Fp2{fe_neg(a.c0), fe_neg(a.c1)}; }
-ZK_HD Fp2 fe_dbl(const Fp2 &a) { return Fp2{fe_dbl(a.c0), fe_dbl(a.c1)}; }
+ZK_HD Fp2 fe_add(const Fp2 &a, const Fp2 &b) {
+    Fp2 r{fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)};
+    fe_wreduce<4>(r.c0);
+    fe_wreduce<4>(r.c1);
+    return r;
+}
+template <int K> ZK_HD Fp2 fe_sub(const Fp2 &a, const Fp2 &b) {  // inputs < 2p per component
+    Fp2 r{fe_sub_k<2>(a.c0, b.c0), fe_sub_k<2>(a.c1, b.c1)};
+    fe_wreduce<4>(r.c0);
+    fe_wreduce<4>(r.c1);
+    return r;
+}
+template <int K> ZK_HD Fp2 fe_neg(const Fp2 &a) { return Fp2{fe_neg_k<2>(a.c0), fe_neg_k<2>(a.c1)}; }
+ZK_HD Fp2 fe_dbl(const Fp2 &a) {
+    Fp2 r{fe_dbl(a.c0), fe_dbl(a.c1)};
+    fe_wreduce<4>(r.c0);
+    fe_wreduce<4>(r.c1);
+    return r;
+}
+ZK_HD Fp2 fe_triple(const Fp2 &a) {
+    Fp2 r{fe_triple(a.c0), fe_triple(a.c1)};
+    fe_wreduce<8>(r.c0);
+    fe_wreduce<8>(r.c1);
+    return r;
+}
 // Karatsuba: 3 base-field products.
 ZK_HD Fp2 fe_mul(const Fp2 &a, const Fp2 &b) {
-    Fp v0 = fe_mul(a.c0, b.c0);
-    Fp v1 = fe_mul(a.c1, b.c1);
-    Fp s = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
-    return Fp2{fe_sub(v0, v1), fe_sub(fe_sub(s, v0), v1)};
+    const Fp v0 = fe_mul(a.c0, b.c0);
+    const Fp v1 = fe_mul(a.c1, b.c1);
+    const Fp s = fe_mul(fe_add_lazy(a.c0, a.c1), fe_add_lazy(b.c0, b.c1));
+    Fp2 r{fe_sub_k<2>(v0, v1), fe_sub_k<4>(s, fe_add(v0, v1))};
+    fe_wreduce<4>(r.c0);
+    fe_wreduce<8>(r.c1);
+    return r;
 }
 // (c0+c1 i)^2 = (c0+c1)(c0-c1) + 2 c0 c1 i : 2 base-field products.
 ZK_HD Fp2 fe_sqr(const Fp2 &a) {
-    Fp t = fe_mul(a.c0, a.c1);
-    Fp u = fe_mul(fe_add(a.c0, a.c1), fe_sub(a.c0, a.c1));
-    return Fp2{u, fe_dbl(t)};
+    const Fp t = fe_mul(a.c0, a.c1);
+    const Fp u = fe_mul(fe_add_lazy(a.c0, a.c1), fe_sub_k<2>(a.c0, a.c1));
+    Fp2 r{u, fe_dbl(t)};
+    fe_wreduce<4>(r.c1);
+    return r;
 }
 ZK_HD Fp2 fe_inv(const Fp2 &a) {
-    Fp d = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
-    return Fp2{fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};
+    const Fp d = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
+    return Fp2{fe_mul(a.c0, d), fe_neg_k<2>(fe_mul(a.c1, d))};
 }
 ZK_HD Fp2 fe_to_mont(const Fp2 &a) { return Fp2{fe_to_mont(a.c0), fe_to_mont(a.c1)}; }
 ZK_HD Fp2 fe_from_mont(const Fp2 &a) { return Fp2{fe_from_mont(a.c0), fe_from_mont(a.c1)}; }
+ZK_HD Fp2 fe_reduce_full(const Fp2 &a) { return Fp2{fe_reduce_full(a.c0), fe_reduce_full(a.c1)}; }
+
+// Canonical words <-> element, generic over F_p / F_p^2 (Montgomery conversion NOT included).
+ZK_HD Fp fe_load_canonical(const uint32_t *w, Fp *) { return fe_from_words<FpTag>(w); }
+ZK_HD Fp2 fe_load_canonical(const uint32_t *w, Fp2 *) { return Fp2{fe_from_words<FpTag>(w), fe_from_words<FpTag>(w + 8)}; }
+ZK_HD void fe_store_canonical(uint32_t *w, const Fp &a) { fe_to_words(fe_reduce_full(a), w); }
+ZK_HD void fe_store_canonical(uint32_t *w, const Fp2 &a) {
+    fe_to_words(fe_reduce_full(a.c0), w);
+    fe_to_words(fe_reduce_full(a.c1), w + 8);
+}
 
 }  // namespace zk

@@ -12,24 +12,32 @@ namespace zk {
 
 typedef unsigned __int128 u128_t;
 
+template <class Tag> struct HostConst;
+#define ZK_DEFINE_HOST_CONST(TAG, PFX)                                             \
+    template <> struct HostConst<TAG> {                                            \
+        static const uint32_t *mod32() { static const uint32_t v[8] = PFX##_MOD32; return v; }      \
+        static const uint32_t *r1() { static const uint32_t v[8] = PFX##_H_R1; return v; }          \
+        static const uint32_t *r2() { static const uint32_t v[8] = PFX##_H_R2; return v; }          \
+        static const uint32_t *from_dev() { static const uint32_t v[8] = PFX##_H_FROM_DEV; return v; } \
+        static const uint32_t *to_dev() { static const uint32_t v[8] = PFX##_H_TO_DEV; return v; }  \
+    };
+ZK_DEFINE_HOST_CONST(FpTag, ZK_FP)
+ZK_DEFINE_HOST_CONST(FrTag, ZK_FR)
+
+template <class Tag> struct HFe;
+template <class Tag> inline HFe<Tag> fe_mul(const HFe<Tag> &a, const HFe<Tag> &b);
+
 template <class Tag> struct HFe {
     uint64_t l[4];
+    static HFe from_words(const uint32_t *w) {
+        HFe r;
+        for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        return r;
+    }
     static HFe zero() { return HFe{{0, 0, 0, 0}}; }
-    static HFe one() {
-        HFe r;
-        for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)FieldConst<Tag>::r1(2 * i) | ((uint64_t)FieldConst<Tag>::r1(2 * i + 1) << 32);
-        return r;
-    }
-    static HFe modulus() {
-        HFe r;
-        for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)FieldConst<Tag>::mod(2 * i) | ((uint64_t)FieldConst<Tag>::mod(2 * i + 1) << 32);
-        return r;
-    }
-    static HFe r2() {
-        HFe r;
-        for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)FieldConst<Tag>::r2(2 * i) | ((uint64_t)FieldConst<Tag>::r2(2 * i + 1) << 32);
-        return r;
-    }
+    static HFe one() { return from_words(HostConst<Tag>::r1()); }
+    static HFe modulus() { return from_words(HostConst<Tag>::mod32()); }
+    static HFe r2() { return from_words(HostConst<Tag>::r2()); }
     static uint64_t inv64() {  // -m^-1 mod 2^64 by Newton iteration
         uint64_t m0 = modulus().l[0], inv = 1;
         for (int i = 0; i < 6; i++) inv *= 2 - m0 * inv;
@@ -37,15 +45,17 @@ template <class Tag> struct HFe {
     }
     bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
     bool equals(const HFe &b) const { return !memcmp(l, b.l, 32); }
+    // Device element (9x29 limbs, lazy, Montgomery radix 2^261) <-> host element (radix 2^256).
     static HFe from_dev(const Fe<Tag> &a) {
-        HFe r;
-        for (int i = 0; i < 4; i++) r.l[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
-        return r;
+        uint32_t w[8];
+        fe_to_words(fe_reduce_full(a), w);               // V = x * 2^261 mod m, canonical
+        return fe_mul(from_words(w), from_words(HostConst<Tag>::from_dev()));  // V * 2^251 * 2^-256 = x * 2^256
     }
     Fe<Tag> to_dev() const {
-        Fe<Tag> r;
-        for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
-        return r;
+        const HFe v = fe_mul(*this, from_words(HostConst<Tag>::to_dev()));      // h * 2^261 * 2^-256 = x * 2^261
+        uint32_t w[8];
+        for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)v.l[i]; w[2 * i + 1] = (uint32_t)(v.l[i] >> 32); }
+        return fe_from_words<Tag>(w);
     }
 };
 
@@ -101,6 +111,10 @@ template <class Tag> inline HFe<Tag> fe_neg(const HFe<Tag> &a) {
     return fe_sub(HFe<Tag>::zero(), a);
 }
 template <class Tag> inline HFe<Tag> fe_dbl(const HFe<Tag> &a) { return fe_add(a, a); }
+template <class Tag> inline HFe<Tag> fe_triple(const HFe<Tag> &a) { return fe_add(fe_add(a, a), a); }
+// curve.h passes value-bound hints K for the lazy device representation; host elements are always canonical.
+template <int K, class Tag> inline HFe<Tag> fe_sub(const HFe<Tag> &a, const HFe<Tag> &b) { return fe_sub(a, b); }
+template <int K, class Tag> inline HFe<Tag> fe_neg(const HFe<Tag> &a) { return fe_neg(a); }
 template <class Tag> inline HFe<Tag> fe_mul(const HFe<Tag> &a, const HFe<Tag> &b) {
     static const HFe<Tag> m = HFe<Tag>::modulus();
     static const uint64_t inv = HFe<Tag>::inv64();
@@ -166,6 +180,9 @@ inline HFp2 fe_add(const HFp2 &a, const HFp2 &b) { return HFp2{fe_add(a.c0, b.c0
 inline HFp2 fe_sub(const HFp2 &a, const HFp2 &b) { return HFp2{fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
 inline HFp2 fe_neg(const HFp2 &a) { return HFp2{fe_neg(a.c0), fe_neg(a.c1)}; }
 inline HFp2 fe_dbl(const HFp2 &a) { return HFp2{fe_dbl(a.c0), fe_dbl(a.c1)}; }
+inline HFp2 fe_triple(const HFp2 &a) { return HFp2{fe_triple(a.c0), fe_triple(a.c1)}; }
+template <int K> inline HFp2 fe_sub(const HFp2 &a, const HFp2 &b) { return fe_sub(a, b); }
+template <int K> inline HFp2 fe_neg(const HFp2 &a) { return fe_neg(a); }
 inline HFp2 fe_mul(const HFp2 &a, const HFp2 &b) {
     HFp v0 = fe_mul(a.c0, b.c0), v1 = fe_mul(a.c1, b.c1);
     HFp s = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));

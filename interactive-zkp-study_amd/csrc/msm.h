@@ -32,7 +32,7 @@ inline void write_fe_canonical(const HFp2 &a, uint64_t *out) {
     write_fe_canonical(a.c1, out + 4);
 }
 template <class F> inline void write_affine(const Xyzz<typename HostOf<F>::type> &p, uint64_t *out_xy, int *out_is_inf) {
-    constexpr int L = sizeof(F) / 8;  // limbs per coordinate
+    constexpr int L = F::CANON_WORDS / 2;  // 64-bit limbs per coordinate
     if (p.is_inf()) {
         memset(out_xy, 0, 2 * L * 8);
         if (out_is_inf) *out_is_inf = 1;

@@ -26,24 +26,20 @@
 namespace zk {
 
 // ------------------------------------------------------------------------------ device helpers
-template <class T> __device__ __forceinline__ Fe<T> ld_fe(const uint32_t *p) {
+// NW canonical 32-bit words (NW = 8 or 16) with 16-byte loads.
+template <int NW> __device__ __forceinline__ void ld_words(const uint32_t *p, uint32_t w[NW]) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 a = q[0], b = q[1];
-    Fe<T> r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+        const uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
 }
-
-template <class F> struct FieldIO;
-template <> struct FieldIO<Fp> {
-    static constexpr int WORDS = 8;
-    static __device__ __forceinline__ Fp load_canonical(const uint32_t *p) { return ld_fe<FpTag>(p); }
-};
-template <> struct FieldIO<Fp2> {
-    static constexpr int WORDS = 16;
-    static __device__ __forceinline__ Fp2 load_canonical(const uint32_t *p) { return Fp2{ld_fe<FpTag>(p), ld_fe<FpTag>(p + 8)}; }
-};
+template <class F> __device__ __forceinline__ F ld_canonical(const uint32_t *p) {
+    uint32_t w[F::CANON_WORDS];
+    ld_words<F::CANON_WORDS>(p, w);
+    return fe_load_canonical(w, (F *)nullptr);
+}
 
 // ------------------------------------------------------------------------------ prepare
 // digits[w * n_pad + i] = signed digit d in [-2^(C-1), 2^(C-1)-1] of scalar i for window w.
@@ -53,7 +49,7 @@ __global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__rest
                                                           Affine<F> *__restrict__ pts_m,
                                                           int16_t *__restrict__ digits, uint32_t n, uint32_t n_pad) {
     constexpr int W = (255 + C - 1) / C;
-    constexpr int PW = FieldIO<F>::WORDS;
+    constexpr int PW = F::CANON_WORDS;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     if (i >= n) {
@@ -61,12 +57,13 @@ __global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__rest
         for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
         return;
     }
-    F x = FieldIO<F>::load_canonical(points + (size_t)i * 2 * PW);
-    F y = FieldIO<F>::load_canonical(points + (size_t)i * 2 * PW + PW);
-    const bool inf = x.is_zero() && y.is_zero();
+    const F x = ld_canonical<F>(points + (size_t)i * 2 * PW);
+    const F y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
+    const bool inf = x.is_zero() && y.is_zero();  // canonical inputs: infinity is the all-zero encoding
     pts_m[i] = Affine<F>{fe_to_mont(x), fe_to_mont(y)};
 
-    const Fr s = ld_fe<FrTag>(scalars + (size_t)i * 8);
+    uint32_t s[8];
+    ld_words<8>(scalars + (size_t)i * 8, s);
     uint32_t carry = 0;
 #pragma unroll
     for (int w = 0; w < W; w++) {
@@ -74,8 +71,8 @@ __global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__rest
         const int off = w * C, word = off >> 5, sh = off & 31;
         uint32_t raw = 0;
         if (word < 8) {
-            raw = s.l[word] >> sh;
-            if (sh + C > 32 && word + 1 < 8) raw |= s.l[word + 1] << (32 - sh);
+            raw = s[word] >> sh;
+            if (sh + C > 32 && word + 1 < 8) raw |= s[word + 1] << (32 - sh);
         }
         raw &= mask;
         uint32_t v = raw + carry;
@@ -200,7 +197,7 @@ __global__ __launch_bounds__(256) void msm_groupscan_kernel(const uint32_t *__re
 // equal length; each thread then adds its points in XYZZ mixed coordinates (8M+2S per point),
 // with the next (index, point) pair fetched while the current addition runs.
 template <class F>
-__global__ __launch_bounds__(256, (sizeof(F) <= 32 ? 3 : 1)) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(256, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts,
                                                              const uint32_t *__restrict__ bucket_off, Xyzz<F> *__restrict__ buckets,
                                                              uint32_t nbuckets) {
@@ -233,7 +230,7 @@ __global__ __launch_bounds__(256, (sizeof(F) <= 32 ? 3 : 1)) void msm_accumulate
                 e2 = lst[k];
                 p2 = pts[e2 & 0x7fffffffu];
             }
-            if (e >> 31) p.y = fe_neg(p.y);
+            if (e >> 31) p.y = fe_neg<2>(p.y);
             xyzz_add_affine(acc, p);
             e = e2;
             p = p2;

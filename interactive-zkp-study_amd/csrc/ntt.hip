@@ -21,17 +21,35 @@ constexpr int NTT_G = 3;     // log2 adjacent elements per digit value
 __device__ __forceinline__ Fr lds_ld(const uint32_t *base, uint32_t stride, uint32_t slot) {
     Fr r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = base[i * stride + slot];
+    for (int i = 0; i < NL; i++) r.l[i] = base[i * stride + slot];
     return r;
 }
 __device__ __forceinline__ void lds_st(uint32_t *base, uint32_t stride, uint32_t slot, const Fr &v) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) base[i * stride + slot] = v.l[i];
+    for (int i = 0; i < NL; i++) base[i * stride + slot] = v.l[i];
+}
+// canonical element (8 words, 32 B) <-> lazy limbs
+__device__ __forceinline__ Fr ld_canon(const uint32_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = q[0], b = q[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fe_from_words<FrTag>(w);
+}
+__device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
+    uint32_t w[8];
+    fe_to_words(fe_reduce_full(v), w);
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
-// LDS: data[8][tile] (limb-major) | tw[8][2^(lp-1)]
-template <bool FINAL>
-__global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__ in, Fr *__restrict__ out,
+// One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
+// passes (lazy 9-limb form, 36 B); only the first load and the last store use the canonical
+// 32-byte encoding.  LDS: data[9][tile] (limb-major) | tw[9][2^(lp-1)].
+//   IN_CANON : `in` holds canonical elements (first pass), else lazy Fr elements (scratch)
+//   FINAL    : last pass: contiguous digit, digit-reversed (natural-order) canonical store
+template <bool FINAL, bool IN_CANON>
+__global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict__ in_v, void *__restrict__ out_v,
                                                           const Fr *__restrict__ tile_tw, const Fr *__restrict__ twA,
                                                           const Fr *__restrict__ twB, Fr scale, NttPassParams P) {
     extern __shared__ uint32_t lds[];
@@ -40,7 +58,9 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__
     const uint32_t tile = 1u << (lp + g);
     const uint32_t ntw = lp ? (1u << (lp - 1)) : 1u;
     uint32_t *data = lds;
-    uint32_t *tw = lds + 8 * tile;
+    uint32_t *tw = lds + NL * tile;
+    const uint32_t *in_c = static_cast<const uint32_t *>(in_v);
+    const Fr *in_l = static_cast<const Fr *>(in_v);
 
     for (uint32_t i = t; i < ntw; i += NTT_NT) lds_st(tw, ntw, i, tile_tw[(size_t)i << P.tw_shift]);
 
@@ -52,7 +72,8 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__
         base_addr = (hi << (P.sp + lp)) + (mid << g);
         for (uint32_t e = t; e < tile; e += NTT_NT) {
             const uint32_t j = e >> g, c = e & (G - 1u);
-            lds_st(data, tile, e, in[(size_t)base_addr + ((size_t)j << P.sp) + c]);
+            const size_t addr = (size_t)base_addr + ((size_t)j << P.sp) + c;
+            lds_st(data, tile, e, IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
         }
     } else {
         const uint32_t lmid_tot = (P.nmid > 0 ? P.lmid[0] : 0) + (P.nmid > 1 ? P.lmid[1] : 0);
@@ -61,7 +82,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__
         for (uint32_t e = t; e < tile; e += NTT_NT) {
             const uint32_t c = e >> lp, j = e & ((1u << lp) - 1u);
             const size_t addr = ((size_t)(k1_base + c) << (P.L - P.l1)) + ((size_t)mid_in << lp) + j;
-            lds_st(data, tile, (j << g) | c, in[addr]);
+            lds_st(data, tile, (j << g) | c, IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
         }
     }
     __syncthreads();
@@ -76,13 +97,16 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__
             const uint32_t sa = (j << g) | c, sb = sa + (half << g);
             const Fr a = lds_ld(data, tile, sa), bb = lds_ld(data, tile, sb);
             const Fr w = lds_ld(tw, ntw, jl << (lp - 1 - s));
-            lds_st(data, tile, sa, fe_add(a, bb));
-            lds_st(data, tile, sb, fe_mul(fe_sub(a, bb), w));
+            Fr sum = fe_add(a, bb);                       // < 4r
+            fe_wreduce<4>(sum);                           // < 2r
+            lds_st(data, tile, sa, sum);
+            lds_st(data, tile, sb, fe_mul(fe_sub_k<2>(a, bb), w));  // (a - b + 2r) < 4r, w < r  ->  < 2r
         }
         __syncthreads();
     }
 
     if (!FINAL) {
+        Fr *out_l = static_cast<Fr *>(out_v);
         const uint32_t sh = P.L - lp - P.sp;
         for (uint32_t e = t; e < tile; e += NTT_NT) {
             const uint32_t k = e >> g, c = e & (G - 1u);
@@ -90,11 +114,12 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__
             Fr x = lds_ld(data, tile, (jpos << g) | c);
             const uint32_t rem = (mid << g) + c;
             const uint32_t ex = (k * rem) << sh;
-            const Fr w = fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);
-            x = fe_mul(x, w);
-            out[(size_t)base_addr + ((size_t)k << P.sp) + c] = x;
+            const Fr w = fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);   // table entries < r
+            x = fe_mul(x, w);                                                      // 2 * 2 < 169  ->  < 2r
+            out_l[(size_t)base_addr + ((size_t)k << P.sp) + c] = x;
         }
     } else {
+        uint32_t *out_c = static_cast<uint32_t *>(out_v);
         uint32_t kmid = mid_in, lmid_tot = 0;
         if (P.nmid == 1) {
             lmid_tot = P.lmid[0];
@@ -109,27 +134,27 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const Fr *__restrict__
             Fr x = lds_ld(data, tile, (jpos << g) | c);
             if (P.apply_scale) x = fe_mul(x, scale);
             const size_t oidx = (size_t)(k1_base + c) + (((size_t)kmid + ((size_t)k << lmid_tot)) << P.l1);
-            out[oidx] = x;
+            st_canon(out_c + oidx * 8, x);
         }
     }
 }
 
-// x[j] *= A[j & mask] * B[j >> lh]   (two-level table of powers g^j, Montgomery form)
-__global__ __launch_bounds__(256) void fr_scale_powers_kernel(Fr *__restrict__ x, const Fr *__restrict__ A, const Fr *__restrict__ B,
+// x[j] *= A[j & mask] * B[j >> lh]   (two-level table of powers g^j, Montgomery form); canonical in/out
+__global__ __launch_bounds__(256) void fr_scale_powers_kernel(uint32_t *__restrict__ x, const Fr *__restrict__ A, const Fr *__restrict__ B,
                                                               uint32_t lh, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Fr w = fe_mul(A[i & ((1u << lh) - 1u)], B[i >> lh]);
-    x[i] = fe_mul(x[i], w);
+    st_canon(x + i * 8, fe_mul(ld_canon(x + i * 8), w));
 }
 
-__global__ __launch_bounds__(256) void fr_quotient_kernel(Fr *__restrict__ out, const Fr *__restrict__ a, const Fr *__restrict__ b,
-                                                          const Fr *__restrict__ c, Fr zr, Fr zr2, size_t n) {
+__global__ __launch_bounds__(256) void fr_quotient_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                          const uint32_t *__restrict__ c, Fr zr, Fr zr2, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     // canonical in/out: mont_mul(a,b) = ab/R; times z*R^2 -> ab*z;  mont_mul(c, z*R) = c*z
-    const Fr ab = fe_mul(fe_mul(a[i], b[i]), zr2);
-    out[i] = fe_sub(ab, fe_mul(c[i], zr));
+    const Fr ab = fe_mul(fe_mul(ld_canon(a + i * 8), ld_canon(b + i * 8)), zr2);
+    st_canon(out + i * 8, fe_sub_k<2>(ab, fe_mul(ld_canon(c + i * 8), zr)));
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -137,11 +162,9 @@ static HFr hfr_pow_u64(HFr a, uint64_t e) {
     uint64_t ee[4] = {e, 0, 0, 0};
     return fe_pow(a, ee);
 }
-static HFr root_of_unity(unsigned L) {  // w_n = 5^((r-1)/2^L), Montgomery form
-    const uint32_t w28[8] = ZK_FR_ROOT28_M;
-    Fr d;
-    for (int i = 0; i < 8; i++) d.l[i] = w28[i];
-    HFr w = HFr::from_dev(d);
+static HFr root_of_unity(unsigned L) {  // w_n = 5^((r-1)/2^L), host Montgomery form
+    const uint32_t w28[8] = ZK_FR_ROOT28_H;
+    HFr w = HFr::from_words(w28);
     for (unsigned i = L; i < ZK_FR_TWO_ADICITY; i++) w = fe_sqr(w);
     return w;
 }
@@ -170,8 +193,9 @@ NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     if (digits_.size() > 1) tmp_.alloc(((size_t)1 << L_) * sizeof(Fr));
     static bool attr_done = false;
     if (!attr_done) {
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        ZK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        const void *fns[4] = {reinterpret_cast<const void *>(&ntt_pass_kernel<false, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<false, false>),
+                              reinterpret_cast<const void *>(&ntt_pass_kernel<true, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<true, false>)};
+        for (const void *f : fns) ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;
     }
 }
@@ -208,7 +232,7 @@ void NttPlan::coset_tables(const uint64_t k[4], bool inverse) {
 
 void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st) {
     const size_t n = (size_t)1 << L_;
-    Fr *data = static_cast<Fr *>(d_data);
+    uint32_t *data = static_cast<uint32_t *>(d_data);
     const int dir = inverse ? 1 : 0;
     const unsigned D = (unsigned)digits_.size();
     const unsigned blocks_sc = (unsigned)((n + 255) / 256);
@@ -227,22 +251,30 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
             P.tw_shift = lmax_ - lp;
             const bool final_pass = (p == D - 1);
             P.g = (D == 1) ? 0 : NTT_G;
-            const Fr *src = (p == 0) ? data : tmp_.as<Fr>();
-            Fr *dst = final_pass ? data : tmp_.as<Fr>();
+            const void *src = (p == 0) ? static_cast<const void *>(data) : tmp_.p;
+            void *dst = final_pass ? static_cast<void *>(data) : tmp_.p;
             const uint32_t tile = 1u << (lp + P.g);
-            const size_t lds = ((size_t)8 * tile + 8 * (lp ? (1u << (lp - 1)) : 1u)) * sizeof(uint32_t);
+            const size_t lds = ((size_t)NL * tile + NL * (lp ? (1u << (lp - 1)) : 1u)) * sizeof(uint32_t);
             const unsigned blocks = (unsigned)(n >> (lp + P.g));
             if (!final_pass) {
                 const Fr *B = (inverse && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
-                hipLaunchKernelGGL((ntt_pass_kernel<false>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
-                                   twA_[dir].as<Fr>(), B, scale_inv_, P);
+                if (p == 0)
+                    hipLaunchKernelGGL((ntt_pass_kernel<false, true>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                                       twA_[dir].as<Fr>(), B, scale_inv_, P);
+                else
+                    hipLaunchKernelGGL((ntt_pass_kernel<false, false>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                                       twA_[dir].as<Fr>(), B, scale_inv_, P);
             } else {
                 P.l1 = (D == 1) ? 0 : digits_[0];
                 P.nmid = D > 2 ? D - 2 : 0;
                 for (unsigned q = 0; q < P.nmid; q++) P.lmid[q] = digits_[1 + q];
                 P.apply_scale = (inverse && D == 1) ? 1 : 0;
-                hipLaunchKernelGGL((ntt_pass_kernel<true>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
-                                   twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
+                if (D == 1)
+                    hipLaunchKernelGGL((ntt_pass_kernel<true, true>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                                       twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
+                else
+                    hipLaunchKernelGGL((ntt_pass_kernel<true, false>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                                       twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
             }
         }
     }
@@ -258,8 +290,9 @@ void fr_quotient(void *d_out, const void *d_a, const void *d_b, const void *d_c,
     memcpy(z.l, zinv, 32);
     const HFr zr = fe_to_mont(z), zr2 = fe_to_mont(zr);
     if (n == 0) return;
-    hipLaunchKernelGGL(fr_quotient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<Fr *>(d_out),
-                       static_cast<const Fr *>(d_a), static_cast<const Fr *>(d_b), static_cast<const Fr *>(d_c), zr.to_dev(), zr2.to_dev(), n);
+    hipLaunchKernelGGL(fr_quotient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out),
+                       static_cast<const uint32_t *>(d_a), static_cast<const uint32_t *>(d_b), static_cast<const uint32_t *>(d_c), zr.to_dev(),
+                       zr2.to_dev(), n);
     ZK_HIP(hipGetLastError());
 }
 

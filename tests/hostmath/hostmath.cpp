@@ -1,27 +1,45 @@
 // tests/hostmath/hostmath.cpp -- TEST-ONLY host build of the device math headers (field.h, curve.h).
-// Lets the CPU test-suite check the exact code the HIP kernels run (limb arithmetic, XYZZ formulas,
-// exceptional cases) against the oracle without a GPU.  Not part of the product library.
+// Lets the CPU test-suite check the exact code the HIP kernels run (9x29-bit lazy limb arithmetic,
+// Montgomery conversions, XYZZ formulas, exceptional cases) against the oracle without a GPU, and
+// the host epilogue types of host_field.h (device <-> host conversions).  Not part of the product.
 #include <string.h>
 #include "curve.h"
+#include "host_field.h"
 using namespace zk;
 
-template <class T> static Fe<T> load4(const uint64_t *p) {
-    Fe<T> r;
-    for (int i = 0; i < 4; i++) { r.l[2 * i] = (uint32_t)p[i]; r.l[2 * i + 1] = (uint32_t)(p[i] >> 32); }
-    return r;
+static void words_of(const uint64_t *p, uint32_t w[8]) {
+    for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)p[i]; w[2 * i + 1] = (uint32_t)(p[i] >> 32); }
 }
-template <class T> static void store4(uint64_t *p, const Fe<T> &a) {
-    for (int i = 0; i < 4; i++) p[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+static void words_to(uint64_t *p, const uint32_t w[8]) {
+    for (int i = 0; i < 4; i++) p[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+template <class T> static Fe<T> load4(const uint64_t *p) {
+    uint32_t w[8];
+    words_of(p, w);
+    return fe_from_words<T>(w);
+}
+template <class T> static void store4(uint64_t *p, const Fe<T> &a) {  // a: any lazy representative
+    uint32_t w[8];
+    fe_to_words(fe_reduce_full(a), w);
+    words_to(p, w);
 }
 template <class T> static void field_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *o) {
     Fe<T> x = fe_to_mont(load4<T>(a)), y = fe_to_mont(load4<T>(b)), r;
     switch (op) {
         case 0: r = fe_add(x, y); break;
-        case 1: r = fe_sub(x, y); break;
+        case 1: r = fe_sub_k<2>(x, y); break;
         case 2: r = fe_mul(x, y); break;
         case 3: r = fe_inv(x); break;
-        case 4: r = fe_neg(x); break;
-        default: r = fe_sqr(x); break;
+        case 4: r = fe_neg_k<2>(x); break;
+        case 5: r = fe_sqr(x); break;
+        case 6: r = fe_mul(fe_add_lazy(x, y), fe_add_lazy(y, y)); break;          // lazy operands: (x+y)*(2y)
+        case 7: {                                                               // worst-case bounds: (x+8m-y)^2 chain
+            Fe<T> t = fe_sub_k<8>(x, y);                                        // < 10m
+            r = fe_mul(fe_sqr(t), t);
+            break;
+        }
+        case 8: r = fe_dbl(fe_triple(x)); break;                                // 6x
+        default: r = x.equals(y) ? Fe<T>::one() : Fe<T>::zero(); break;
     }
     store4(o, fe_from_mont(r));
 }
@@ -39,12 +57,27 @@ static void g2_store(uint64_t *o, const G2Xyzz &p) {
     store4(o, fe_from_mont(a.x.c0)); store4(o + 4, fe_from_mont(a.x.c1));
     store4(o + 8, fe_from_mont(a.y.c0)); store4(o + 12, fe_from_mont(a.y.c1));
 }
-static void k32(const uint64_t *k, uint32_t out[8]) {
-    for (int i = 0; i < 4; i++) { out[2 * i] = (uint32_t)k[i]; out[2 * i + 1] = (uint32_t)(k[i] >> 32); }
-}
+static void k32(const uint64_t *k, uint32_t out[8]) { words_of(k, out); }
+
 extern "C" {
 void hm_field_op(int which, int op, const uint64_t *a, const uint64_t *b, uint64_t *o) {
     if (which) field_op<FrTag>(op, a, b, o); else field_op<FpTag>(op, a, b, o);
+}
+// device element -> host epilogue element -> canonical, and back: exercises HFe::from_dev / to_dev
+void hm_host_roundtrip(int which, const uint64_t *a, uint64_t *via_host, uint64_t *via_dev) {
+    if (which) {
+        Fr x = fe_to_mont(load4<FrTag>(a));
+        HFr h = HFr::from_dev(fe_add(x, Fr::zero()));
+        HFr c = fe_from_mont(h);
+        memcpy(via_host, c.l, 32);
+        store4(via_dev, fe_from_mont(h.to_dev()));
+    } else {
+        Fp x = fe_to_mont(load4<FpTag>(a));
+        HFp h = HFp::from_dev(fe_sub_k<8>(x, Fp::zero()));  // a lazy representative (value + 8p)
+        HFp c = fe_from_mont(h);
+        memcpy(via_host, c.l, 32);
+        store4(via_dev, fe_from_mont(h.to_dev()));
+    }
 }
 void hm_g1_mul(const uint64_t *p, const uint64_t *k, uint64_t *o) {
     uint32_t kk[8]; k32(k, kk);
@@ -81,5 +114,19 @@ void hm_g2_add(int mode, const uint64_t *p, const uint64_t *q, const uint64_t *k
 }
 void hm_g1_small_mul(const uint64_t *p, uint32_t k, uint64_t *o) {
     g1_store(o, xyzz_small_mul(G1Xyzz::from_affine(g1_load(p)), k));
+}
+// sum of n affine points through the mixed-add accumulator, then the host epilogue conversion
+// (device XYZZ -> host XYZZ -> affine), as the MSM tail does.
+void hm_g1_accumulate(const uint64_t *pts, uint32_t n, const uint8_t *negate, uint64_t *o) {
+    G1Xyzz acc = G1Xyzz::inf();
+    for (uint32_t i = 0; i < n; i++) {
+        G1Affine q = g1_load(pts + 8 * i);
+        if (negate && negate[i]) q = affine_neg(q);
+        xyzz_add_affine(acc, q);
+    }
+    Xyzz<HFp> h{HFp::from_dev(acc.x), HFp::from_dev(acc.y), HFp::from_dev(acc.zz), HFp::from_dev(acc.zzz)};
+    Affine<HFp> a = xyzz_to_affine(h);
+    HFp x = fe_from_mont(a.x), y = fe_from_mont(a.y);
+    memcpy(o, x.l, 32); memcpy(o + 4, y.l, 32);
 }
 }

@@ -98,3 +98,49 @@ def test_small_mul(hm):
         Ai, O = co.g1_to_arr([A]), np.zeros(8, dtype=np.uint64)
         hm.hm_g1_small_mul(P(Ai), ctypes.c_uint32(k), P(O))
         assert co.g1_from_arr(O)[0] == o.g1_multiply(A, k)
+
+
+def test_lazy_bounds_and_equality(hm):
+    """Operands at the edge of fe_mul's contract: unnormalised sums, values up to 10m, 6x."""
+    rnd = random.Random(4)
+    for which, m in ((0, o.P), (1, o.R)):
+        vals = [0, 1, m - 1, m - 2] + [rnd.randrange(m) for _ in range(200)]
+        for i in range(len(vals) - 1):
+            a, b = vals[i], vals[i + 1]
+            assert fop(hm, which, 6, a, b) == (a + b) * (2 * b) % m
+            assert fop(hm, which, 7, a, b) == pow(a - b, 3, m)
+            assert fop(hm, which, 8, a) == 6 * a % m
+            assert fop(hm, which, 9, a, b) == (1 if a == b else 0)
+            assert fop(hm, which, 9, a, a) == 1
+
+
+def test_device_host_conversions(hm):
+    rnd = random.Random(5)
+    for which, m in ((0, o.P), (1, o.R)):
+        for a in [0, 1, m - 1] + [rnd.randrange(m) for _ in range(50)]:
+            A, H, D = co.to_limbs([a]), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+            hm.hm_host_roundtrip(which, P(A), P(H), P(D))
+            assert co.from_limbs(H)[0] == a and co.from_limbs(D)[0] == a
+
+
+def test_long_accumulation_chain_keeps_bounds(hm):
+    """300 mixed additions in one accumulator (the bucket loop), with negations, a repeated point
+    (doubling branch) and a cancelling pair, then the host epilogue conversion."""
+    rnd = random.Random(6)
+    n = 300
+    ks = [rnd.randrange(1, o.R) for _ in range(n)]
+    ks[10] = ks[9]
+    pts = co.g1_from_arr(co.g1_fixed_base_arr(o.G1, co.to_limbs(ks)))
+    neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
+    neg[9] = neg[10] = 0
+    neg[21], ks[21] = 1 - neg[20], ks[20]
+    pts[21] = pts[20]
+    total = sum((-k if s else k) for k, s in zip(ks, neg)) % o.R
+    O = np.zeros(8, dtype=np.uint64)
+    hm.hm_g1_accumulate(P(co.g1_to_arr(pts)), ctypes.c_uint32(n), P(neg), P(O))
+    assert co.g1_from_arr(O)[0] == co.g1_mul(o.G1, total)
+    # everything cancels -> infinity
+    pts2 = [pts[0], pts[0], pts[1], pts[1]]
+    neg2 = np.array([0, 1, 1, 0], dtype=np.uint8)
+    hm.hm_g1_accumulate(P(co.g1_to_arr(pts2)), ctypes.c_uint32(4), P(neg2), P(O))
+    assert not O.any()
