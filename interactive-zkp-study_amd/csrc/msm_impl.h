@@ -123,20 +123,38 @@ template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint3
 //   PLACE pass: counts -> exclusive offsets (block scan + group base), LDS-atomic cursors,
 //               entries (point index | sign << 31) written to sorted[] (each workgroup's output
 //               region is one contiguous, L2-resident span).
+//   Both passes also build the size ranking of the buckets (a counting sort of the bucket ids by
+//   list length, longest first): COUNT adds a per-workgroup LDS histogram of the lengths to
+//   size_hist[]; PLACE reserves one span per (workgroup, length) with a single global atomic and
+//   writes the bucket ids into perm[], so the accumulate kernel's wavefronts get equal-length lists.
 constexpr int SORT_NT = 1024;
 constexpr int SORT_BPG = 2048;
+constexpr int SIZE_BINS = 1024;  // list lengths >= SIZE_BINS-1 share the top bin
+
+struct SortBufs {
+    uint32_t *counts;       // [W*nb]   list length of every bucket
+    uint32_t *bucket_off;   // [W*nb]   start of every bucket's list inside sorted[]
+    uint32_t *group_base;   // [groups] exclusive scan of group_total
+    uint32_t *group_total;  // [groups] entries per (window, bucket group)
+    uint32_t *sorted;       // [W*n]    point index | sign << 31
+    uint32_t *size_hist;    // [SIZE_BINS] buckets per list length (zeroed by the scan kernel after use)
+    uint32_t *size_base;    // [SIZE_BINS] first rank of each length, longest first
+    uint32_t *size_cursor;  // [SIZE_BINS] running reservation (zeroed by the scan kernel)
+    uint32_t *perm;         // [W*nb]   bucket ids ordered by decreasing list length
+};
 
 template <bool PLACE>
-__global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__restrict__ digits, uint32_t *__restrict__ counts,
-                                                           uint32_t *__restrict__ bucket_off, const uint32_t *__restrict__ group_base,
-                                                           uint32_t *__restrict__ group_total, uint32_t *__restrict__ sorted,
-                                                           uint32_t n_pad, uint32_t nb) {
+__global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t nb) {
     __shared__ uint32_t cnt[SORT_BPG];
+    __shared__ uint32_t hist[SIZE_BINS];
     __shared__ uint32_t wave_tot[SORT_NT / 64 + 1];
+    uint32_t *__restrict__ counts = B.counts;
+    uint32_t *__restrict__ sorted = B.sorted;
     const uint32_t t = threadIdx.x, g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
     const uint32_t base = g * SORT_BPG;
     const uint32_t nloc = min((uint32_t)SORT_BPG, nb - base);
     const size_t flat0 = (size_t)w * nb + base;
+    hist[t] = 0;  // SIZE_BINS == SORT_NT
     if (!PLACE) {
         cnt[2 * t] = 0;
         cnt[2 * t + 1] = 0;
@@ -144,11 +162,25 @@ __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__rest
         const uint32_t c0 = (2 * t < nloc) ? counts[flat0 + 2 * t] : 0u;
         const uint32_t c1 = (2 * t + 1 < nloc) ? counts[flat0 + 2 * t + 1] : 0u;
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total) + group_base[w * G + g];
+        const uint32_t ex = block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total) + B.group_base[w * G + g];
         cnt[2 * t] = ex;
         cnt[2 * t + 1] = ex + c0;
-        if (2 * t < nloc) bucket_off[flat0 + 2 * t] = ex;
-        if (2 * t + 1 < nloc) bucket_off[flat0 + 2 * t + 1] = ex + c0;
+        if (2 * t < nloc) B.bucket_off[flat0 + 2 * t] = ex;
+        if (2 * t + 1 < nloc) B.bucket_off[flat0 + 2 * t + 1] = ex + c0;
+        // size ranking: local rank inside this workgroup's share of each length bin ...
+        const uint32_t b0 = min(c0, (uint32_t)SIZE_BINS - 1u), b1 = min(c1, (uint32_t)SIZE_BINS - 1u);
+        uint32_t r0 = 0, r1 = 0;
+        if (2 * t < nloc) r0 = atomicAdd(&hist[b0], 1u);
+        if (2 * t + 1 < nloc) r1 = atomicAdd(&hist[b1], 1u);
+        __syncthreads();
+        // ... one global reservation per non-empty bin ...
+        const uint32_t h = hist[t];
+        __syncthreads();
+        hist[t] = h ? B.size_base[t] + atomicAdd(&B.size_cursor[t], h) : 0u;
+        __syncthreads();
+        // ... and the bucket ids go to their ranks
+        if (2 * t < nloc) B.perm[hist[b0] + r0] = (uint32_t)(flat0 + 2 * t);
+        if (2 * t + 1 < nloc) B.perm[hist[b1] + r1] = (uint32_t)(flat0 + 2 * t + 1);
     }
     __syncthreads();
     const uint4 *dv = reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad);
@@ -171,53 +203,56 @@ __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__rest
     if (!PLACE) {
         __syncthreads();
         const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
-        if (2 * t < nloc) counts[flat0 + 2 * t] = c0;
-        if (2 * t + 1 < nloc) counts[flat0 + 2 * t + 1] = c1;
+        if (2 * t < nloc) {
+            counts[flat0 + 2 * t] = c0;
+            atomicAdd(&hist[min(c0, (uint32_t)SIZE_BINS - 1u)], 1u);
+        }
+        if (2 * t + 1 < nloc) {
+            counts[flat0 + 2 * t + 1] = c1;
+            atomicAdd(&hist[min(c1, (uint32_t)SIZE_BINS - 1u)], 1u);
+        }
         uint32_t total;
-        (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);
-        if (t == 0) group_total[w * G + g] = total;
+        (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);  // contains the barriers hist needs
+        if (t == 0) B.group_total[w * G + g] = total;
+        const uint32_t h = hist[t];
+        if (h) atomicAdd(&B.size_hist[t], h);
     }
 }
 
-// Exclusive scan of the (<= 256) group totals; one workgroup.
+// One workgroup: exclusive scan of the (<= 256) group totals, and of the list-length histogram in
+// DEcreasing length order (rank 0 = longest lists).  Leaves size_hist / size_cursor zeroed for the
+// next run (they start zeroed at plan creation).
 template <int DUMMY>
-__global__ __launch_bounds__(256) void msm_groupscan_kernel(const uint32_t *__restrict__ group_total, uint32_t *__restrict__ group_base,
-                                                            uint32_t ngroups) {
-    __shared__ uint32_t wave_tot[8];
+__global__ __launch_bounds__(SIZE_BINS) void msm_scan_kernel(SortBufs B, uint32_t ngroups) {
+    __shared__ uint32_t wave_tot[SIZE_BINS / 64 + 1];
     const uint32_t t = threadIdx.x;
-    const uint32_t v = t < ngroups ? group_total[t] : 0u;
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan<256>(v, wave_tot, &total);
-    if (t < ngroups) group_base[t] = ex;
+    const uint32_t v = t < ngroups ? B.group_total[t] : 0u;
+    const uint32_t ex = block_exclusive_scan<SIZE_BINS>(v, wave_tot, &total);
+    if (t < ngroups) B.group_base[t] = ex;
+    const uint32_t bin = SIZE_BINS - 1u - t;  // thread 0 takes the longest lists
+    const uint32_t hv = B.size_hist[bin];
+    const uint32_t hx = block_exclusive_scan<SIZE_BINS>(hv, wave_tot, &total);
+    B.size_base[bin] = hx;
+    B.size_hist[bin] = 0;
+    B.size_cursor[bin] = 0;
 }
 
 // ------------------------------------------------------------------------------ accumulate
-// One thread per bucket over the flattened (window-major) bucket array.  The 256 buckets of a
-// workgroup are ranked by size in LDS so that the lanes of a wavefront own buckets of (nearly)
-// equal length; each thread then adds its points in XYZZ mixed coordinates (8M+2S per point),
-// with the next (index, point) pair fetched while the current addition runs.
+// One thread per bucket, one wavefront per workgroup, buckets taken in order of decreasing list
+// length (perm[]): the 64 lanes of a wavefront own lists of (nearly) equal length, wavefronts retire
+// independently and the longest lists start first.  Each thread adds its points in XYZZ mixed
+// coordinates (8M+2S per point), the next (index, point) pair being fetched under the current add.
 template <class F>
-__global__ __launch_bounds__(256, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts,
-                                                             const uint32_t *__restrict__ bucket_off, Xyzz<F> *__restrict__ buckets,
+                                                             const uint32_t *__restrict__ bucket_off,
+                                                             const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
                                                              uint32_t nbuckets) {
-    __shared__ uint32_t s_cnt[256];
-    __shared__ uint32_t s_perm[256];
-    const uint32_t t = threadIdx.x, b0 = blockIdx.x * 256;
-    const uint32_t c = (b0 + t < nbuckets) ? counts[b0 + t] : 0u;
-    s_cnt[t] = c;
-    __syncthreads();
-    uint32_t rank = 0;
-    for (uint32_t u = 0; u < 256; u++) {
-        const uint32_t cu = s_cnt[u];
-        rank += (cu > c || (cu == c && u < t)) ? 1u : 0u;
-    }
-    s_perm[rank] = t;
-    __syncthreads();
-    const uint32_t mine = s_perm[t];
-    const uint32_t b = b0 + mine;
-    if (b >= nbuckets) return;
-    const uint32_t len = s_cnt[mine];
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= nbuckets) return;
+    const uint32_t b = perm[r];
+    const uint32_t len = counts[b];
     Xyzz<F> acc = Xyzz<F>::inf();
     if (len) {
         const uint32_t *lst = sorted + bucket_off[b];
@@ -332,7 +367,7 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, arena, partial, out;
+    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, size_bins, perm, arena, partial, out;
     PinnedBuf h_out;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
 
@@ -357,6 +392,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         bucket_off.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
         group_tot.alloc(256 * sizeof(uint32_t));
         group_base.alloc(256 * sizeof(uint32_t));
+        size_bins.alloc(3 * SIZE_BINS * sizeof(uint32_t));  // size_hist | size_base | size_cursor
+        ZK_HIP(hipMemset(size_bins.p, 0, 3 * SIZE_BINS * sizeof(uint32_t)));
+        perm.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
         arena.alloc(ar);
         partial.alloc((size_t)32 * 16 * ODD_MAX_CHUNKS * sizeof(Xyzz<F>));
         out.alloc(outn);
@@ -383,15 +421,24 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const uint32_t G = (nb + SORT_BPG - 1) / SORT_BPG;
         if (G * W > 256) throw std::runtime_error("zk_msm: too many bucket groups");
         const dim3 grid(G, W);
-        hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), counts.as<uint32_t>(),
-                           bucket_off.as<uint32_t>(), group_base.as<uint32_t>(), group_tot.as<uint32_t>(), sorted.as<uint32_t>(), n_pad, nb);
-        hipLaunchKernelGGL((msm_groupscan_kernel<0>), dim3(1), dim3(256), 0, st, group_tot.as<uint32_t>(), group_base.as<uint32_t>(), G * W);
-        hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), counts.as<uint32_t>(),
-                           bucket_off.as<uint32_t>(), group_base.as<uint32_t>(), group_tot.as<uint32_t>(), sorted.as<uint32_t>(), n_pad, nb);
+        SortBufs B;
+        B.counts = counts.as<uint32_t>();
+        B.bucket_off = bucket_off.as<uint32_t>();
+        B.group_base = group_base.as<uint32_t>();
+        B.group_total = group_tot.as<uint32_t>();
+        B.sorted = sorted.as<uint32_t>();
+        B.size_hist = size_bins.as<uint32_t>();
+        B.size_base = B.size_hist + SIZE_BINS;
+        B.size_cursor = B.size_hist + 2 * SIZE_BINS;
+        B.perm = perm.as<uint32_t>();
+        hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
+        hipLaunchKernelGGL((msm_scan_kernel<0>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
+        hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
         mark(2, st);
         const uint32_t nbuckets = W * nb;
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 255) / 256), dim3(256), 0, st, pts_m.as<Affine<F>>(),
-                           sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), arena.as<Xyzz<F>>(), nbuckets);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<Affine<F>>(),
+                           sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), perm.as<uint32_t>(),
+                           arena.as<Xyzz<F>>(), nbuckets);
     }
 
     // Enqueues the GPU pipeline and reads the window/level sums back; returns the XYZZ result.

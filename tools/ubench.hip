@@ -86,7 +86,7 @@ __global__ void k_selfcheck(const Fp *a, const Fp *b, Fp *mul, Fp *add, Fp *sub,
     if (i >= n) return;
     mul[i] = fe_mul(a[i], b[i]);
     add[i] = fe_add(a[i], b[i]);
-    sub[i] = fe_sub(a[i], b[i]);
+    sub[i] = fe_sub_k<2>(a[i], b[i]);
 }
 __global__ void k_selfcheck_g1(const G1Affine *g, const uint32_t *k, G1Xyzz *out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,19 +141,19 @@ int main() {
     std::vector<Fp> ha(N), hb(N), hm(N), hs(N), hd(N);
     srand(1);
     for (int i = 0; i < N; i++) {
-        for (int j = 0; j < 8; j++) { ha[i].l[j] = rand() * 65537u + rand(); hb[i].l[j] = rand() * 65537u + rand(); }
-        ha[i].l[7] &= 0x1fffffff; hb[i].l[7] &= 0x1fffffff;  // < p
+        for (int j = 0; j < NL; j++) { ha[i].l[j] = (rand() * 65537u + rand()) & LMASK; hb[i].l[j] = (rand() * 65537u + rand()) & LMASK; }
+        ha[i].l[NL - 1] &= 0x1fffff; hb[i].l[NL - 1] &= 0x1fffff;  // < p
     }
     Fp *da, *db, *dm, *ds, *dd;
-    CK(hipMalloc(&da, N * 32)); CK(hipMalloc(&db, N * 32)); CK(hipMalloc(&dm, N * 32)); CK(hipMalloc(&ds, N * 32)); CK(hipMalloc(&dd, N * 32));
-    CK(hipMemcpy(da, ha.data(), N * 32, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), N * 32, hipMemcpyHostToDevice));
+    CK(hipMalloc(&da, N * sizeof(Fp))); CK(hipMalloc(&db, N * sizeof(Fp))); CK(hipMalloc(&dm, N * sizeof(Fp))); CK(hipMalloc(&ds, N * sizeof(Fp))); CK(hipMalloc(&dd, N * sizeof(Fp)));
+    CK(hipMemcpy(da, ha.data(), N * sizeof(Fp), hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), N * sizeof(Fp), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_selfcheck, dim3(N / 256), dim3(256), 0, 0, da, db, dm, ds, dd, N);
-    CK(hipMemcpy(hm.data(), dm, N * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs.data(), ds, N * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(hd.data(), dd, N * 32, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hm.data(), dm, N * sizeof(Fp), hipMemcpyDeviceToHost)); CK(hipMemcpy(hs.data(), ds, N * sizeof(Fp), hipMemcpyDeviceToHost)); CK(hipMemcpy(hd.data(), dd, N * sizeof(Fp), hipMemcpyDeviceToHost));
     int bad = 0;
     for (int i = 0; i < N; i++) {
         if (!hm[i].equals(fe_mul(ha[i], hb[i]))) bad++;
         if (!hs[i].equals(fe_add(ha[i], hb[i]))) bad++;
-        if (!hd[i].equals(fe_sub(ha[i], hb[i]))) bad++;
+        if (!hd[i].equals(fe_sub_k<2>(ha[i], hb[i]))) bad++;
     }
     printf("selfcheck field (device vs host, %d cases): %s (%d mismatches)\n", 3 * N, bad ? "FAIL" : "ok", bad);
     {
