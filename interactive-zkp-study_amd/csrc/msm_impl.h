@@ -275,86 +275,79 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumul
 }
 
 // ------------------------------------------------------------------------------ reduce
-// out[i] = in[2i] + in[2i+1] over the flattened (window-major) level array.
+// Per window: R_w = sum_j (j+1) * B_j = T + sum_l 2^l * O_l, where T is the plain sum of the
+// window's buckets and O_l the plain sum of the ODD entries of level l of the pairwise-sum tree
+// (L_0 = B, L_{l+1}[j] = L_l[2j] + L_l[2j+1]); no serial running sum anywhere.  Everything runs IN
+// PLACE in the bucket array x[]:
+//   pair step s:       x[i * 2^(s+1)] += x[i * 2^(s+1) + 2^s]       (level s+1 lives at stride 2^(s+1))
+//   the odd entries of level l sit at x[2^l * (2j+1)] and are never written again by pair steps, so
+//   their plain sum is a second in-place tree over j:  x[2^l (2j+1)] += x[2^l (2(j + 2^k) + 1)],
+//   which for level l starts one step after pair step l.  At step s the pair tree and the odd trees
+//   of all lower levels together need (s+1) * (half >> s) <= half additions: one EC addition per
+//   thread per step, depth = number of levels.
+// Afterwards O_l = x[2^l] and T = x[0] (per block for the block kernel, per window at the end).
 template <class F>
-__global__ __launch_bounds__(256) void msm_pair_kernel(const Xyzz<F> *__restrict__ in, Xyzz<F> *__restrict__ out, uint32_t n_out) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_out) return;
-    Xyzz<F> a = in[2 * (size_t)i];
-    const Xyzz<F> b = in[2 * (size_t)i + 1];
-    xyzz_add(a, b);
-    out[i] = a;
-}
-
-template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
-    Xyzz<F> r;
-    constexpr int NW = sizeof(Xyzz<F>) / 4;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
-    return r;
-}
-template <class F> __device__ __forceinline__ Xyzz<F> wave_sum_xyzz(Xyzz<F> v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        Xyzz<F> o = shfl_down_xyzz(v, d);
-        xyzz_add(v, o);
-    }
-    return v;  // valid in lane 0
-}
-
-struct LevelTable {
-    uint32_t level_off[20];  // element offset of level l inside the arena
-    uint32_t nb;             // buckets per window at level 0
-    uint32_t levels;         // log2(nb)
-    uint32_t windows;
-};
-constexpr int ODD_SERIAL = 4;                  // items summed serially per lane
-constexpr int ODD_CHUNK = 64 * ODD_SERIAL;     // odd items per wave
-constexpr int ODD_MAX_CHUNKS = 64;             // nb/2 / ODD_CHUNK <= 64 for nb <= 2^15
-
-// Stage 1: grid = (ODD_MAX_CHUNKS, levels * windows), one wave per block.
-// partial[(g * ODD_MAX_CHUNKS) + chunk] = sum of odd entries [chunk*256, chunk*256+256) of level l, window w.
-template <class F>
-__global__ __launch_bounds__(64) void msm_oddsum1_kernel(const Xyzz<F> *__restrict__ arena, Xyzz<F> *__restrict__ partial, LevelTable lt) {
-    const uint32_t g = blockIdx.y, l = g / lt.windows, w = g % lt.windows;
-    const uint32_t m = lt.nb >> l;  // items per window at level l
-    const uint32_t nodd = m >> 1;
-    const uint32_t chunk = blockIdx.x;
-    if (chunk * ODD_CHUNK >= nodd) return;
-    const Xyzz<F> *lv = arena + lt.level_off[l] + (size_t)w * m;
-    const uint32_t lane = threadIdx.x;
-    Xyzz<F> acc = Xyzz<F>::inf();
-#pragma unroll 1
-    for (int s = 0; s < ODD_SERIAL; s++) {
-        const uint32_t q = chunk * ODD_CHUNK + s * 64 + lane;
-        if (q < nodd) {
-            const Xyzz<F> it = lv[2 * (size_t)q + 1];
-            xyzz_add(acc, it);
+__global__ __launch_bounds__(256) void msm_reduce_block_kernel(Xyzz<F> *x, uint32_t BL) {
+    Xyzz<F> *blk = x + ((size_t)blockIdx.x << BL);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t s = 0; s < BL; s++) {
+        const uint32_t sh = BL - 1 - s, per = 1u << sh;  // additions per tree at this step
+        const uint32_t ntasks = (s + 1) * per;
+        for (uint32_t q = t; q < ntasks; q += blockDim.x) {
+            const uint32_t grp = q >> sh, i = q & (per - 1u);
+            uint32_t dst, src;
+            if (grp == s) {  // pair tree, level s -> s+1
+                dst = i << (s + 1);
+                src = dst + (1u << s);
+            } else {  // odd tree of level grp, its step k
+                const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
+                dst = (2 * j + 1) << l;
+                src = (2 * (j + (1u << k)) + 1) << l;
+            }
+            Xyzz<F> a = blk[dst];
+            const Xyzz<F> b = blk[src];
+            xyzz_add(a, b);
+            blk[dst] = a;
         }
+        __syncthreads();  // the workgroup's waves share one CU (one L1): workgroup-scope visibility
     }
-    acc = wave_sum_xyzz(acc);
-    if (lane == 0) partial[(size_t)g * ODD_MAX_CHUNKS + chunk] = acc;
 }
-// Stage 2: grid = levels * windows (+ windows blocks that copy the totals); one wave per block.
-// out[w * (levels + 1) + l] = O_{w,l};  out[w * (levels + 1) + levels] = T_w (single item of the last level).
+
+// One workgroup per window: the upper levels of the pair tree over the block totals (and their odd
+// trees), plus, for every level below BL, the plain sum over the blocks of that level's per-block
+// odd partial.  Then out[w][l] = O_l (l < levels), out[w][levels] = T.
 template <class F>
-__global__ __launch_bounds__(64) void msm_oddsum2_kernel(const Xyzz<F> *__restrict__ arena, const Xyzz<F> *__restrict__ partial,
-                                                         Xyzz<F> *__restrict__ out, LevelTable lt) {
-    const uint32_t g = blockIdx.x, lane = threadIdx.x;
-    if (g >= lt.levels * lt.windows) {  // totals
-        const uint32_t w = g - lt.levels * lt.windows;
-        if (lane == 0) out[(size_t)w * (lt.levels + 1) + lt.levels] = arena[lt.level_off[lt.levels] + w];
-        return;
+__global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz<F> *__restrict__ out, uint32_t nb, uint32_t BL,
+                                                                uint32_t levels) {
+    Xyzz<F> *win = x + (size_t)blockIdx.x * nb;
+    const uint32_t t = threadIdx.x;
+    const uint32_t UL = levels - BL;  // log2(blocks per window)
+    for (uint32_t s = 0; s < UL; s++) {
+        const uint32_t sh = UL - 1 - s, per = 1u << sh;
+        const uint32_t ntasks = (s + 1 + BL) * per;
+        for (uint32_t q = t; q < ntasks; q += blockDim.x) {
+            const uint32_t grp = q >> sh, i = q & (per - 1u);
+            uint32_t dst, src;
+            if (grp == s) {  // upper pair tree
+                dst = (i << (s + 1)) << BL;
+                src = dst + ((1u << s) << BL);
+            } else if (grp < s) {  // odd tree of upper level BL + grp
+                const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
+                dst = ((2 * j + 1) << l) << BL;
+                src = ((2 * (j + (1u << k)) + 1) << l) << BL;
+            } else {  // plain sum over blocks of the per-block odd partial of level l < BL
+                const uint32_t l = grp - s - 1;
+                dst = ((i << (s + 1)) << BL) + (1u << l);
+                src = dst + ((1u << s) << BL);
+            }
+            Xyzz<F> a = win[dst];
+            const Xyzz<F> b = win[src];
+            xyzz_add(a, b);
+            win[dst] = a;
+        }
+        __syncthreads();
     }
-    const uint32_t l = g / lt.windows, w = g % lt.windows;
-    const uint32_t nodd = (lt.nb >> l) >> 1;
-    const uint32_t nchunks = (nodd + ODD_CHUNK - 1) / ODD_CHUNK;
-    Xyzz<F> acc = Xyzz<F>::inf();
-    if (lane < nchunks) acc = partial[(size_t)g * ODD_MAX_CHUNKS + lane];
-    acc = wave_sum_xyzz(acc);
-    if (lane == 0) out[(size_t)w * (lt.levels + 1) + l] = acc;
+    if (t <= levels) out[(size_t)blockIdx.x * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -367,7 +360,7 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, size_bins, perm, arena, partial, out;
+    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, size_bins, perm, arena, out;
     PinnedBuf h_out;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
 
@@ -383,20 +376,19 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             if (c > pick_window_bits(max_n)) continue;
             size_t W = (255 + c - 1) / c, nb = (size_t)1 << (c - 1);
             dig = std::max(dig, W * n_pad * sizeof(int16_t));
-            ar = std::max(ar, 2 * W * nb * sizeof(Xyzz<F>));
+            ar = std::max(ar, W * nb * sizeof(Xyzz<F>));
             outn = std::max(outn, W * (size_t)c * sizeof(Xyzz<F>));
         }
         digits.alloc(dig);
         sorted.alloc(dig * 2);  // one 4-byte entry per (window, point)
-        counts.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
-        bucket_off.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
+        counts.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
+        bucket_off.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         group_tot.alloc(256 * sizeof(uint32_t));
         group_base.alloc(256 * sizeof(uint32_t));
         size_bins.alloc(3 * SIZE_BINS * sizeof(uint32_t));  // size_hist | size_base | size_cursor
         ZK_HIP(hipMemset(size_bins.p, 0, 3 * SIZE_BINS * sizeof(uint32_t)));
-        perm.alloc(ar / (2 * sizeof(Xyzz<F>)) * sizeof(uint32_t));
+        perm.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         arena.alloc(ar);
-        partial.alloc((size_t)32 * 16 * ODD_MAX_CHUNKS * sizeof(Xyzz<F>));
         out.alloc(outn);
         h_out.alloc(outn);
     }
@@ -459,21 +451,13 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         launch_sort_accumulate(n_pad, nb, W, st);
         mark(3, st);
 
-        LevelTable lt;
-        lt.nb = nb; lt.levels = levels; lt.windows = W;
-        uint32_t o = 0;
-        for (uint32_t l = 0; l <= levels; l++) {
-            lt.level_off[l] = o;
-            o += W * (nb >> l);
+        {
+            Xyzz<F> *ar = arena.as<Xyzz<F>>();
+            const uint32_t BL = std::min<uint32_t>(9, levels);
+            const uint32_t threads = std::max<uint32_t>(64, 1u << (BL - 1));
+            hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3((W * nb) >> BL), dim3(threads), 0, st, ar, BL);
+            hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, st, ar, out.as<Xyzz<F>>(), nb, BL, levels);
         }
-        Xyzz<F> *ar = arena.as<Xyzz<F>>();
-        for (uint32_t l = 0; l < levels; l++) {
-            const uint32_t n_out = W * (nb >> (l + 1));
-            hipLaunchKernelGGL((msm_pair_kernel<F>), dim3((n_out + 255) / 256), dim3(256), 0, st, ar + lt.level_off[l],
-                               ar + lt.level_off[l + 1], n_out);
-        }
-        hipLaunchKernelGGL((msm_oddsum1_kernel<F>), dim3(ODD_MAX_CHUNKS, levels * W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), lt);
-        hipLaunchKernelGGL((msm_oddsum2_kernel<F>), dim3(levels * W + W), dim3(64), 0, st, ar, partial.as<Xyzz<F>>(), out.as<Xyzz<F>>(), lt);
         mark(4, st);
         const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
         ZK_HIP(hipMemcpyAsync(h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
