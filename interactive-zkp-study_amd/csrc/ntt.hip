@@ -288,7 +288,10 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
 void fr_quotient(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, hipStream_t st) {
     HFr z;
     memcpy(z.l, zinv, 32);
-    const HFr zr = fe_to_mont(z), zr2 = fe_to_mont(zr);
+    // device Montgomery radix is 2^261: zr -> z*2^261, zr2 -> z*2^522 (host radix 2^256 differs, so the
+    // second factor 2^261 is multiplied in explicitly before the host->device conversion)
+    const HFr zr = fe_to_mont(z);
+    const HFr zr2 = fe_mul(zr, fe_to_mont(HFr::from_words(HostConst<FrTag>::to_dev())));
     if (n == 0) return;
     hipLaunchKernelGGL(fr_quotient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out),
                        static_cast<const uint32_t *>(d_a), static_cast<const uint32_t *>(d_b), static_cast<const uint32_t *>(d_c), zr.to_dev(),

@@ -1,0 +1,205 @@
+"""Groth16 at scale on the GPU backend: roots-of-unity QAP, H(x) by NTT, proof elements by MSM.
+
+The reference's Groth16 flow (zkp/groth16/{qap_creator_lcm,poly_utils,setup,proving}.py) works on
+the integer domain {1..k} with float Lagrange interpolation, a dense W x G coefficient matrix and
+an O(W^2) `hxr` (poly_utils.py:116-125) -- none of which can reach 2^20 constraints (SURVEY.md
+section 7 "hard parts", section 8 row A7).  This module keeps the reference's CRS *shape* and proof
+formulas (sigma1_1, sigma1_2 = powers of x in G1, sigma1_4 = per-wire L query, sigma1_5 = H query,
+sigma2_1, sigma2_2; proof_a/b/c of proving.py:23-75) and swaps the polynomial side for the standard
+at-scale one:
+
+  * QAP over H = {w^k}: A_i(w^k) = A[k][i], so the coefficient vectors u_A = R.A, u_B, u_C that the
+    reference builds with `_multiply_vec_matrix` are inverse NTTs of the per-constraint dot products;
+  * H(x) = (A(x)B(x) - C(x)) / (x^m - 1): 3 iNTT + 3 coset NTT + pointwise quotient + 1 coset iNTT
+    (7 transforms of size m) instead of schoolbook multiply + long division;
+  * proof_A = alpha*G1 + MSM(u_A, sigma1_2) + r*delta*G1, and so on: one device MSM per query.
+
+Everything stays resident in HBM (torch tensors used as plain device buffers); correctness at any
+size is checked against closed-form scalars computed from the known toxic waste
+(zkp/groth16/test.py:303-325: proof_A == A*G1, proof_B == B*G2, proof_C == C*G1).
+"""
+import numpy as np
+
+from .. import _lib
+from ..device import MsmPlan, NttPlan, fr_quotient
+from ..field import CURVE_ORDER as R, G1, G2, fixed_base_mul, g1_to_limbs, g2_to_limbs, msm_g1, limbs_to_g1
+
+COSET_SHIFT = 5  # the reference's coset generator (zkp/plonk/utils.py:166-167)
+
+
+def _batch_inverse(vals):
+    """Montgomery's trick on Python ints mod r."""
+    n = len(vals)
+    pref = [1] * (n + 1)
+    for i, v in enumerate(vals):
+        pref[i + 1] = pref[i] * v % R
+    inv = pow(pref[n], -1, R)
+    out = [0] * n
+    for i in range(n - 1, -1, -1):
+        out[i] = pref[i] * inv % R
+        inv = inv * vals[i] % R
+    return out
+
+
+class ChainCircuit:
+    """Synthetic R1CS with m = 2^log_m constraints t_{k+1} = t_k * t_k + t_k + c_k.
+
+    Wires: 0 = one, 1 + k = t_k (k = 0..m); public wires [0, 1] (the reference's default
+    pub_r_indexs).  Row k:  A = t_k,  B = t_k,  C = t_{k+1} - t_k - c_k * one  (<= 3 non-zeros)."""
+
+    def __init__(self, log_m, seed=1):
+        self.log_m = log_m
+        self.m = 1 << log_m
+        rng = np.random.default_rng(seed)
+        self.consts = [int(v) for v in rng.integers(1, 1 << 30, size=self.m)]
+        self.t0 = int(rng.integers(2, 1 << 62))
+        self.num_wires = self.m + 2
+        self.pub = [0, 1]
+
+    def witness(self):
+        """-> (w, a_evals, b_evals, c_evals): the wire values and the per-constraint products."""
+        t = [0] * (self.m + 1)
+        t[0] = self.t0
+        for k in range(self.m):
+            t[k + 1] = (t[k] * t[k] + t[k] + self.consts[k]) % R
+        w = [1] + t
+        a = t[:self.m]
+        c = [(t[k + 1] - t[k] - self.consts[k]) % R for k in range(self.m)]
+        return w, a, list(a), c
+
+    def lagrange_at(self, x):
+        """[L_k(x)] for the domain H = {w^k}: L_k(x) = (x^m - 1)/m * w^k / (x - w^k)."""
+        m = self.m
+        omega = pow(5, (R - 1) // m, R)
+        roots, cur = [], 1
+        for _ in range(m):
+            roots.append(cur)
+            cur = cur * omega % R
+        zx = (pow(x, m, R) - 1) % R
+        inv = _batch_inverse([(x - wk) % R for wk in roots])
+        scale = zx * pow(m, -1, R) % R
+        return [scale * roots[k] % R * inv[k] % R for k in range(m)], zx
+
+    def qap_at(self, x):
+        """Per-wire evaluations A_i(x), B_i(x), C_i(x) and Z(x) (lists of length num_wires)."""
+        L, zx = self.lagrange_at(x)
+        m, W = self.m, self.num_wires
+        A = [0] * W
+        C = [0] * W
+        for k in range(m):
+            A[1 + k] = L[k]
+        C[0] = (-sum(self.consts[k] * L[k] for k in range(m))) % R
+        for k in range(m):
+            C[1 + k] = (C[1 + k] - L[k]) % R
+            C[2 + k] = (C[2 + k] + L[k]) % R
+        return A, list(A), C, zx
+
+
+def _dev(arr):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).cuda()
+
+
+class ScaleCRS:
+    """Device-resident CRS in the reference's sigma layout (zkp/groth16/setup.py:15-69)."""
+
+    def __init__(self, circuit, alpha, beta, gamma, delta, x_val):
+        self.circuit = circuit
+        m, W = circuit.m, circuit.num_wires
+        self.toxic = dict(alpha=alpha % R, beta=beta % R, gamma=gamma % R, delta=delta % R, x=x_val % R)
+        Ax, Bx, Cx, zx = circuit.qap_at(x_val)
+        self.Ax, self.Bx, self.Cx, self.Zx = Ax, Bx, Cx, zx
+        dinv = pow(delta, -1, R)
+        powers, cur = [], 1
+        for _ in range(m):
+            powers.append(cur)
+            cur = cur * x_val % R
+        # sigma1_1 / sigma2_1 (setup.py:15-16, 62-63)
+        self.sigma1_1 = fixed_base_mul(G1, [alpha, beta, delta])
+        self.sigma2_1 = fixed_base_mul(G2, [beta, gamma, delta])
+        lib = _lib.load()
+        S = _lib.ints_to_limbs(powers)
+        g1 = g1_to_limbs([G1])
+        g2 = g2_to_limbs([G2])
+        # sigma1_2 = [x^j]_1, sigma2_2 = [x^j]_2  (setup.py:18-23, 65-69)
+        s12 = np.zeros((m, 8), dtype=np.uint64)
+        _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(S), m, _lib.ptr(s12)))
+        s22 = np.zeros((m, 16), dtype=np.uint64)
+        _lib.check(lib.zk_fixed_base_g2(_lib.ptr(g2), _lib.ptr(S), m, _lib.ptr(s22)))
+        # sigma1_4: L query for private wires; placeholders (zeros) at the public indices (setup.py:42-54)
+        lq = [0 if i in circuit.pub else (beta * Ax[i] + alpha * Bx[i] + Cx[i]) % R * dinv % R for i in range(W)]
+        self.l_scalars = lq
+        s14 = np.zeros((W, 8), dtype=np.uint64)
+        _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(lq)), W, _lib.ptr(s14)))
+        for i in circuit.pub:
+            s14[i] = 0
+        # sigma1_5 = [x^k Z(x) / delta]_1, k < m - 1  (setup.py:56-60)
+        hq = [powers[k] * zx % R * dinv % R for k in range(m - 1)]
+        s15 = np.zeros((m - 1, 8), dtype=np.uint64)
+        _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(hq)), m - 1, _lib.ptr(s15)))
+        self.h_sigma1_2_head = limbs_to_g1(s12[:2])
+        self.d_s12, self.d_s22, self.d_s14, self.d_s15 = _dev(s12), _dev(s22), _dev(s14), _dev(s15)
+
+
+class ScaleProver:
+    """Plans + scratch for proving against one ScaleCRS."""
+
+    def __init__(self, crs):
+        import torch
+        self.crs = crs
+        c = crs.circuit
+        self.m, self.W = c.m, c.num_wires
+        self.ntt = NttPlan(c.log_m)
+        self.g1 = MsmPlan(_lib.GROUP_G1, self.W)
+        self.g2 = MsmPlan(_lib.GROUP_G2, self.m)
+        self.scratch = [torch.empty((self.m, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+        self.zinv = pow((pow(COSET_SHIFT, self.m, R) - 1) % R, -1, R)  # 1 / Z_H on the coset k*H
+
+    def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
+        """d_a, d_b, d_c: device (m, 4) evaluations sum_i w_i A[k][i] etc.; d_w: device (W, 4) witness.
+        The three evaluation buffers are overwritten with the coefficient vectors u_A, u_B, u_C.
+        -> (proof_A, proof_B, proof_C) as points, plus the H coefficients' device buffer."""
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        m, W, crs = self.m, self.W, self.crs
+        ca, cb, cc, h = self.scratch
+        # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.)
+        for d in (d_a, d_b, d_c):
+            self.ntt.run(d.data_ptr(), True, None, st)
+        # H = (A*B - C) / Z on the coset 5*H
+        ca.copy_(d_a)
+        cb.copy_(d_b)
+        cc.copy_(d_c)
+        for d in (ca, cb, cc):
+            self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
+        fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
+        self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
+        # queries
+        msm_a = self.g1.run(d_a.data_ptr(), crs.d_s12.data_ptr(), m, st)
+        msm_b2 = self.g2.run(d_b.data_ptr(), crs.d_s22.data_ptr(), m, st)
+        msm_b1 = self.g1.run(d_b.data_ptr(), crs.d_s12.data_ptr(), m, st)
+        msm_l = self.g1.run(d_w.data_ptr(), crs.d_s14.data_ptr(), W, st)   # placeholders at public wires are infinity
+        msm_h = self.g1.run(h.data_ptr(), crs.d_s15.data_ptr(), m - 1, st)
+        from ..field import msm_g2
+        r, s = r % R, s % R
+        s11, s21 = crs.sigma1_1, crs.sigma2_1
+        proof_a = msm_g1([1, 1, r], [msm_a, s11[0], s11[2]])                      # proving.py:23-33
+        proof_b = msm_g2([1, 1, s], [msm_b2, s21[0], s21[2]])                     # proving.py:35-45
+        # proving.py:47-75 with the +-r*s*delta terms cancelled:  s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H
+        proof_c = msm_g1([s, r, r, 1, 1], [proof_a, s11[1], msm_b1, msm_l, msm_h])
+        return proof_a, proof_b, proof_c, h
+
+
+def closed_form_scalars(crs, witness, r, s):
+    """(A, B, C) in F_r with proof_A = A*G1, proof_B = B*G2, proof_C = C*G1  (zkp/groth16/test.py:303-325)."""
+    t = crs.toxic
+    W = crs.circuit.num_wires
+    a_x = sum(witness[i] * crs.Ax[i] for i in range(W)) % R
+    b_x = sum(witness[i] * crs.Bx[i] for i in range(W)) % R
+    c_x = sum(witness[i] * crs.Cx[i] for i in range(W)) % R
+    A = (t["alpha"] + a_x + r * t["delta"]) % R
+    B = (t["beta"] + b_x + s * t["delta"]) % R
+    h_x = (a_x * b_x - c_x) % R * pow(crs.Zx, -1, R) % R
+    priv = sum(witness[i] * crs.l_scalars[i] for i in range(W)) % R   # already divided by delta, public entries are 0
+    C = (priv + h_x * crs.Zx % R * pow(t["delta"], -1, R) + A * s + B * r - r * s * t["delta"]) % R
+    return A, B, C

@@ -1,0 +1,48 @@
+"""GPU test (-m gpu): Groth16 prove at scale (roots-of-unity QAP, H by NTT, queries by MSM; SURVEY.md
+section 8 row A7 / BASELINE.json configs[3]) against the closed-form scalars the known toxic waste
+gives (zkp/groth16/test.py:303-325), and H(x) against the oracle's schoolbook multiply + long division
+(zkp/groth16/poly_utils.py:17-45) at a size the oracle can reach."""
+import numpy as np
+import pytest
+
+import py_ref as o
+from zkhip import _lib
+from zkhip.field import G1, G2, ec_mul
+from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver, closed_form_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(ints):
+    import torch
+    return torch.from_numpy(_lib.ints_to_limbs(ints).view(np.int64)).cuda()
+
+
+@pytest.mark.parametrize("log_m", [4, 10, 13])
+def test_scale_prover_closed_form(log_m):
+    import torch
+    circ = ChainCircuit(log_m, seed=3)
+    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 200))
+    w, a, b, c = circ.witness()
+    assert all(a[k] * b[k] % o.R == c[k] for k in range(0, circ.m, max(1, circ.m // 64)))  # R1CS satisfied
+    prover = ScaleProver(crs)
+    r, s = 4106, 4565
+    d_a, d_b, d_c, d_w = _dev(a), _dev(b), _dev(c), _dev(w)
+    pa, pb, pc, h = prover.prove(d_a, d_b, d_c, d_w, r, s)
+    A, B, C = closed_form_scalars(crs, w, r, s)
+    assert pa == ec_mul(G1, A)
+    assert pb == ec_mul(G2, B)
+    assert pc == ec_mul(G1, C)
+    torch.cuda.synchronize()
+    hc = _lib.limbs_to_ints(h.cpu().numpy().view(np.uint64))
+    assert hc[circ.m - 1] == 0                                   # deg H <= m - 2
+    if log_m <= 4:
+        # H against the reference's algorithm: (u_A * u_B - u_C) div (x^m - 1), remainder 0
+        m = circ.m
+        w_m = o.get_root_of_unity(m)
+        uA, uB, uC = o.ifft(a, w_m), o.ifft(b, w_m), o.ifft(c, w_m)
+        P = o.subtract_polys(o.multiply_polys(uA, uB), uC)
+        Z = [(-1) % o.R] + [0] * (m - 1) + [1]
+        q, rem = o.div_polys(P, Z)
+        assert all(v == 0 for v in rem)
+        assert hc[:len(q)] == q
