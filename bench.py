@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of points per GPU")
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 size of the secondary NTT measurement (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="points timed on the pure-Python baseline (0 = skip)")
+    ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -175,6 +176,15 @@ def main():
         extra["ntt"] = {"log_n": L, "ms_per_transform": round(ms, 4), "elements_per_s": m / (ms * 1e-3),
                         "algorithmic_GBps": 64.0 * m / (ms * 1e-3) / 1e9, "hbm_frac": 64.0 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "roundtrip_exact": bool(torch.equal(d, ref))}
+
+    # ---- secondary: Groth16 prove() wall-clock on a synthetic 2^20-constraint R1CS (BASELINE.json configs[3])
+    if args.groth16_log_m and world == 1:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_groth16
+            extra["groth16_prove"] = bench_groth16.run(args.groth16_log_m, 3)
+        except Exception as exc:  # the headline number must not depend on the secondary measurement
+            extra["groth16_prove"] = {"error": repr(exc)}
 
     # ---- CPU baseline: reference-shaped pure-Python path on a bounded sample (rank 0, N = 1 only)
     cpu = None

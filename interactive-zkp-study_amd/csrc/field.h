@@ -295,7 +295,7 @@ template <class Tag> ZK_HD Fe<Tag> fe_from_words(const uint32_t w[8]) {
     }
     return r;
 }
-// Input must be canonical (< m < 2^254), e.g. the result of fe_reduce_full.
+// Input: normalised limbs, value < 2^256 (canonical after fe_reduce_full; lazy values < 4m also fit).
 template <class Tag> ZK_HD void fe_to_words(const Fe<Tag> &a, uint32_t w[8]) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {

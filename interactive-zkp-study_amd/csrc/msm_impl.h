@@ -35,6 +35,27 @@ template <int NW> __device__ __forceinline__ void ld_words(const uint32_t *p, ui
         w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
     }
 }
+// Montgomery-form affine point as stored in the workspace: the lazy coordinates (< 2m < 2^255) are
+// packed back to 32-bit words, so a G1 point is exactly one aligned 64-byte line (one HBM/L2
+// transaction per gather instead of the two a 72-byte limb image straddles).
+template <class F> struct alignas(16) PackedAffine {
+    uint32_t w[2 * F::CANON_WORDS];
+};
+__device__ __forceinline__ void pack_fe(uint32_t *w, const Fp &a) { fe_to_words(a, w); }
+__device__ __forceinline__ void pack_fe(uint32_t *w, const Fp2 &a) {
+    fe_to_words(a.c0, w);
+    fe_to_words(a.c1, w + 8);
+}
+template <class F> __device__ __forceinline__ PackedAffine<F> pack_affine(const Affine<F> &p) {
+    PackedAffine<F> r;
+    pack_fe(r.w, p.x);
+    pack_fe(r.w + F::CANON_WORDS, p.y);
+    return r;
+}
+template <class F> __device__ __forceinline__ Affine<F> unpack_affine(const PackedAffine<F> &p) {
+    return Affine<F>{fe_load_canonical(p.w, (F *)nullptr), fe_load_canonical(p.w + F::CANON_WORDS, (F *)nullptr)};
+}
+
 template <class F> __device__ __forceinline__ F ld_canonical(const uint32_t *p) {
     uint32_t w[F::CANON_WORDS];
     ld_words<F::CANON_WORDS>(p, w);
@@ -46,7 +67,7 @@ template <class F> __device__ __forceinline__ F ld_canonical(const uint32_t *p) 
 template <class F, int C>
 __global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__restrict__ scalars,
                                                           const uint32_t *__restrict__ points,
-                                                          Affine<F> *__restrict__ pts_m,
+                                                          PackedAffine<F> *__restrict__ pts_m,
                                                           int16_t *__restrict__ digits, uint32_t n, uint32_t n_pad) {
     constexpr int W = (255 + C - 1) / C;
     constexpr int PW = F::CANON_WORDS;
@@ -60,7 +81,7 @@ __global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__rest
     const F x = ld_canonical<F>(points + (size_t)i * 2 * PW);
     const F y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
     const bool inf = x.is_zero() && y.is_zero();  // canonical inputs: infinity is the all-zero encoding
-    pts_m[i] = Affine<F>{fe_to_mont(x), fe_to_mont(y)};
+    pts_m[i] = pack_affine(Affine<F>{fe_to_mont(x), fe_to_mont(y)});
 
     uint32_t s[8];
     ld_words<8>(scalars + (size_t)i * 8, s);
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(SIZE_BINS) void msm_scan_kernel(SortBufs B, uint32_
 // independently and the longest lists start first.  Each thread adds its points in XYZZ mixed
 // coordinates (8M+2S per point), the next (index, point) pair being fetched under the current add.
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const Affine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts,
                                                              const uint32_t *__restrict__ bucket_off,
                                                              const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
@@ -257,18 +278,19 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumul
     if (len) {
         const uint32_t *lst = sorted + bucket_off[b];
         uint32_t e = lst[0];
-        Affine<F> p = pts[e & 0x7fffffffu];
+        PackedAffine<F> pk = pts[e & 0x7fffffffu];
         for (uint32_t k = 1; k <= len; k++) {
             uint32_t e2 = 0;
-            Affine<F> p2 = p;
+            PackedAffine<F> pk2 = pk;
             if (k < len) {
                 e2 = lst[k];
-                p2 = pts[e2 & 0x7fffffffu];
+                pk2 = pts[e2 & 0x7fffffffu];
             }
+            Affine<F> p = unpack_affine(pk);
             if (e >> 31) p.y = fe_neg<2>(p.y);
             xyzz_add_affine(acc, p);
             e = e2;
-            p = p2;
+            pk = pk2;
         }
     }
     buckets[b] = acc;
@@ -368,7 +390,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
         group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
         size_t n_pad = pad_n(max_n);
-        pts_m.alloc(max_n * sizeof(Affine<F>));
+        pts_m.alloc(max_n * sizeof(PackedAffine<F>));
         // digits: worst case over the window choices available to n <= max_n
         size_t dig = 0, ar = 0, outn = 0;
         const int cs[3] = {8, 12, 16};
@@ -406,7 +428,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     int window_bits(size_t n) const override { return pick_window_bits(n); }
 
     template <int C> void launch_prepare(const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad, hipStream_t st) {
-        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / 256), dim3(256), 0, st, sc, pt, pts_m.as<Affine<F>>(),
+        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / 256), dim3(256), 0, st, sc, pt, pts_m.as<PackedAffine<F>>(),
                            digits.as<int16_t>(), n, n_pad);
     }
     void launch_sort_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
@@ -428,7 +450,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
         mark(2, st);
         const uint32_t nbuckets = W * nb;
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<Affine<F>>(),
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(),
                            sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), perm.as<uint32_t>(),
                            arena.as<Xyzz<F>>(), nbuckets);
     }

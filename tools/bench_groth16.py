@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Groth16 prove() wall-clock on a synthetic 2^log_m-constraint R1CS (BASELINE.json configs[3]):
+witness vectors resident in HBM -> proof (A, B, C); CRS resident on the device.
+    python tools/bench_groth16.py --log-m 20 --reps 3
+Prints one JSON line with the timing breakdown; the proof is checked against the closed-form
+scalars the known toxic waste gives."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
+
+
+def run(log_m, reps):
+    import torch
+    from zkhip import _lib
+    from zkhip.field import G1, G2, ec_mul
+    from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver, closed_form_scalars
+    t0 = time.perf_counter()
+    circ = ChainCircuit(log_m, seed=7)
+    w, a, b, c = circ.witness()
+    t_wit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 201))
+    t_setup = time.perf_counter() - t0
+    prover = ScaleProver(crs)
+    dev = lambda v: torch.from_numpy(_lib.ints_to_limbs(v).view(np.int64)).cuda()
+    A0, B0, C0, W0 = dev(a), dev(b), dev(c), dev(w)
+    r, s = 4106, 4565
+    times = []
+    for _ in range(reps + 1):
+        d_a, d_b, d_c = A0.clone(), B0.clone(), C0.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pa, pb, pc, h = prover.prove(d_a, d_b, d_c, W0, r, s)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    A, B, C = closed_form_scalars(crs, w, r, s)
+    ok = pa == ec_mul(G1, A) and pb == ec_mul(G2, B) and pc == ec_mul(G1, C)
+    return {"log_m": log_m, "constraints": circ.m, "wires": circ.num_wires, "prove_ms": round(min(times[1:]) * 1e3, 3),
+            "prove_ms_all": [round(t * 1e3, 3) for t in times[1:]], "first_call_ms": round(times[0] * 1e3, 3),
+            "witness_gen_s_python": round(t_wit, 2), "setup_s": round(t_setup, 2), "verified_closed_form": bool(ok)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-m", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    print(json.dumps(run(args.log_m, args.reps)), flush=True)
