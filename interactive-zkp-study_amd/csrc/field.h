@@ -32,6 +32,25 @@
 #define ZK_HD inline
 #endif
 
+// Host-only contract checker (tests/hostmath builds with -DZK_FIELD_DEBUG): every element carries an
+// upper bound of its value (in units of the modulus) and of its limbs, every operation checks its
+// precondition from the header comment above and aborts on a violation.
+#if defined(ZK_FIELD_DEBUG) && !defined(__HIPCC__)
+#include <stdio.h>
+#include <stdlib.h>
+#define ZK_DBG(...) __VA_ARGS__
+#define ZK_DBG_ASSERT(cond, what)                                                        \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            fprintf(stderr, "ZK_FIELD_DEBUG: contract violated: %s (%s:%d)\n", what, __FILE__, __LINE__); \
+            abort();                                                                     \
+        }                                                                                \
+    } while (0)
+#else
+#define ZK_DBG(...)
+#define ZK_DBG_ASSERT(cond, what)
+#endif
+
 namespace zk {
 
 struct FpTag {};  // base field   p
@@ -69,6 +88,8 @@ ZK_DEFINE_FIELD_CONST(FrTag, ZK_FR)
 // A field element; value semantics.  l[0..7] < 2^29 when normalised, l[8] holds the rest.
 template <class Tag> struct alignas(4) Fe {
     uint32_t l[NL];
+    ZK_DBG(double vb = 16.0;    /* value < vb * m                      */
+           double lmax = 4.0;   /* every limb < lmax * 2^29 (limbs 0..7) */)
     typedef FieldConst<Tag> C;
     static constexpr int CANON_WORDS = 8;  // 32-bit words of the canonical (ABI) encoding
 
@@ -76,12 +97,14 @@ template <class Tag> struct alignas(4) Fe {
         Fe r;
 #pragma unroll
         for (int i = 0; i < NL; i++) r.l[i] = 0;
+        ZK_DBG(r.vb = 0; r.lmax = 1;)
         return r;
     }
     static ZK_HD Fe one() {  // Montgomery form of 1
         Fe r;
 #pragma unroll
         for (int i = 0; i < NL; i++) r.l[i] = C::r1(i);
+        ZK_DBG(r.vb = 1; r.lmax = 1;)
         return r;
     }
     ZK_HD bool raw_is_zero() const {  // all limbs zero (exact integer zero)
@@ -105,6 +128,7 @@ template <class Tag> ZK_HD void fe_normalize(Fe<Tag> &a) {
         c = t >> LB;  // arithmetic shift: negative limbs borrow
     }
     a.l[NL - 1] = (uint32_t)((int32_t)a.l[NL - 1] + c);
+    ZK_DBG(a.lmax = 1;)
 }
 
 // a - K*m if that is >= 0, else a.  Input normalised.
@@ -124,16 +148,20 @@ template <int K, class Tag> ZK_HD void fe_cond_sub(Fe<Tag> &a) {
 #pragma unroll
         for (int i = 0; i < NL; i++) a.l[i] = d[i];
     }
+    ZK_DBG_ASSERT(a.lmax <= 1, "fe_cond_sub needs normalised limbs");
+    ZK_DBG(a.vb = (a.vb > K) ? ((a.vb - K > K) ? a.vb - K : (double)K) : a.vb;)
 }
 
 // value < M*m (M <= 16)  ->  value < 2m
 template <int M, class Tag> ZK_HD void fe_wreduce(Fe<Tag> &a) {
+    ZK_DBG_ASSERT(a.vb <= M, "fe_wreduce<M>: value bound exceeds M");
     if (M > 8) fe_cond_sub<8>(a);
     if (M > 4) fe_cond_sub<4>(a);
     if (M > 2) fe_cond_sub<2>(a);
 }
 // value < 16m -> canonical representative < m
 template <class Tag> ZK_HD Fe<Tag> fe_reduce_full(Fe<Tag> a) {
+    ZK_DBG_ASSERT(a.vb <= 16, "fe_reduce_full: value bound exceeds 16 m");
     fe_normalize(a);
     fe_cond_sub<8>(a);
     fe_cond_sub<4>(a);
@@ -144,6 +172,7 @@ template <class Tag> ZK_HD Fe<Tag> fe_reduce_full(Fe<Tag> a) {
 
 template <class Tag> ZK_HD bool Fe<Tag>::is_zero() const {
     // Quick reject: a multiple of m below 16m must match k*m in its lowest limb for some k.
+    ZK_DBG_ASSERT(vb <= 16, "is_zero: value bound exceeds 16 m");
     Fe t = *this;
     fe_normalize(t);
     bool maybe = false;
@@ -164,7 +193,10 @@ template <class Tag> ZK_HD Fe<Tag> fe_add(const Fe<Tag> &a, const Fe<Tag> &b) {
     Fe<Tag> r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    ZK_DBG_ASSERT(a.lmax + b.lmax <= 6, "fe_add: limb overflow");
     fe_normalize(r);
+    ZK_DBG(r.vb = a.vb + b.vb;)
+    ZK_DBG_ASSERT(r.vb <= 1024, "fe_add: value too large");
     return r;
 }
 // limb-wise sum without carry propagation: only as a direct operand of fe_mul / fe_sqr
@@ -172,6 +204,7 @@ template <class Tag> ZK_HD Fe<Tag> fe_add_lazy(const Fe<Tag> &a, const Fe<Tag> &
     Fe<Tag> r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    ZK_DBG(r.vb = a.vb + b.vb; r.lmax = a.lmax + b.lmax;)
     return r;
 }
 // a - b + K*m; requires value(b) <= K*m.  Result normalised, value < value(a) + K*m.
@@ -180,7 +213,10 @@ template <int K, class Tag> ZK_HD Fe<Tag> fe_sub_k(const Fe<Tag> &a, const Fe<Ta
     Fe<Tag> r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + C::kp(K, i) - b.l[i];
+    ZK_DBG_ASSERT(b.vb <= K, "fe_sub_k<K>: subtrahend may exceed K*m");
+    ZK_DBG_ASSERT(a.lmax <= 2 && b.lmax <= 3, "fe_sub_k: limb overflow");
     fe_normalize(r);
+    ZK_DBG(r.vb = a.vb + K;)
     return r;
 }
 // K*m - a; requires value(a) <= K*m.
@@ -189,21 +225,27 @@ template <int K, class Tag> ZK_HD Fe<Tag> fe_neg_k(const Fe<Tag> &a) {
     Fe<Tag> r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = C::kp(K, i) - a.l[i];
+    ZK_DBG_ASSERT(a.vb <= K && a.lmax <= 3, "fe_neg_k<K>: operand may exceed K*m");
     fe_normalize(r);
+    ZK_DBG(r.vb = K;)
     return r;
 }
 template <class Tag> ZK_HD Fe<Tag> fe_dbl(const Fe<Tag> &a) {
     Fe<Tag> r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] << 1;
+    ZK_DBG_ASSERT(a.lmax <= 3, "fe_dbl: limb overflow");
     fe_normalize(r);
+    ZK_DBG(r.vb = 2 * a.vb;)
     return r;
 }
 template <class Tag> ZK_HD Fe<Tag> fe_triple(const Fe<Tag> &a) {
     Fe<Tag> r;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] * 3u;
+    ZK_DBG_ASSERT(a.lmax <= 2, "fe_triple: limb overflow");
     fe_normalize(r);
+    ZK_DBG(r.vb = 3 * a.vb;)
     return r;
 }
 
@@ -233,6 +275,9 @@ template <class Tag> ZK_HD Fe<Tag> fe_mul(const Fe<Tag> &a, const Fe<Tag> &b) {
         acc >>= LB;
     }
     r.l[NL - 1] = (uint32_t)acc;
+    ZK_DBG_ASSERT(a.vb * b.vb < 169.0, "fe_mul: value bounds va*vb >= 169");
+    ZK_DBG_ASSERT(9.0 * a.lmax * b.lmax + 9.0 + 1.0 < 64.0, "fe_mul: column accumulator may overflow");  // units of 2^58
+    ZK_DBG(r.vb = a.vb * b.vb / 169.0 + 1.0; r.lmax = 1;)
     return r;
 }
 
@@ -266,6 +311,9 @@ template <class Tag> ZK_HD Fe<Tag> fe_sqr(const Fe<Tag> &a) {
         acc >>= LB;
     }
     r.l[NL - 1] = (uint32_t)acc;
+    ZK_DBG_ASSERT(a.vb * a.vb < 169.0, "fe_sqr: value bound va^2 >= 169");
+    ZK_DBG_ASSERT(9.0 * a.lmax * a.lmax + 9.0 + 1.0 < 64.0 && a.lmax <= 4, "fe_sqr: column accumulator may overflow");
+    ZK_DBG(r.vb = a.vb * a.vb / 169.0 + 1.0; r.lmax = 1;)
     return r;
 }
 
@@ -274,12 +322,14 @@ template <class Tag> ZK_HD Fe<Tag> fe_to_mont(const Fe<Tag> &a) {
     Fe<Tag> r2;
 #pragma unroll
     for (int i = 0; i < NL; i++) r2.l[i] = C::r2(i);
+    ZK_DBG(r2.vb = 1; r2.lmax = 1;)
     return fe_mul(a, r2);
 }
 template <class Tag> ZK_HD Fe<Tag> fe_from_mont(const Fe<Tag> &a) {
     Fe<Tag> one;
 #pragma unroll
     for (int i = 0; i < NL; i++) one.l[i] = (i == 0);
+    ZK_DBG(one.vb = 1; one.lmax = 1;)
     return fe_mul(a, one);
 }
 
@@ -293,10 +343,12 @@ template <class Tag> ZK_HD Fe<Tag> fe_from_words(const uint32_t w[8]) {
         if (sh + LB > 32 && word + 1 < 8) v |= w[word + 1] << (32 - sh);
         r.l[i] = (i < NL - 1) ? (v & LMASK) : v;
     }
+    ZK_DBG(r.vb = 5.3; r.lmax = 1;)  // any 256-bit integer is < 5.3 m; canonical inputs are < m
     return r;
 }
 // Input: normalised limbs, value < 2^256 (canonical after fe_reduce_full; lazy values < 4m also fit).
 template <class Tag> ZK_HD void fe_to_words(const Fe<Tag> &a, uint32_t w[8]) {
+    ZK_DBG_ASSERT(a.vb <= 5.25 && a.lmax <= 1, "fe_to_words: value may not fit 256 bits");
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int bit = 32 * j, li = bit / LB, sh = bit - li * LB;  // word j starts inside limb li
@@ -324,6 +376,7 @@ template <class Tag> ZK_HD Fe<Tag> fe_inv(const Fe<Tag> &a) {
     Fe<Tag> m;
 #pragma unroll
     for (int i = 0; i < NL; i++) m.l[i] = C::mod(i);
+    ZK_DBG(m.vb = 1; m.lmax = 1;)
     m.l[0] -= 2;  // low limb of both moduli is > 2
     uint32_t e[8];
     fe_to_words(m, e);

@@ -15,11 +15,13 @@ import py_ref as o
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def hm():
+@pytest.fixture(scope="module", params=["libhostmath.so", "libhostmath_dbg.so"])
+def hm(request):
+    """Both builds: plain, and -DZK_FIELD_DEBUG (aborts the process if any operation is called
+    outside the value/limb bounds that field.h's lazy reduction relies on)."""
     d = os.path.join(HERE, "hostmath")
     subprocess.check_call(["make", "-s", "-C", d])
-    return ctypes.CDLL(os.path.join(d, "libhostmath.so"))
+    return ctypes.CDLL(os.path.join(d, request.param))
 
 
 def P(a):
