@@ -162,7 +162,18 @@ struct SortBufs {
     uint32_t *size_base;    // [SIZE_BINS] first rank of each length, longest first
     uint32_t *size_cursor;  // [SIZE_BINS] running reservation (zeroed by the scan kernel)
     uint32_t *perm;         // [W*nb]   bucket ids ordered by decreasing list length
+    // Heavy buckets (list longer than heavy_th: skewed / witness-like scalars, degenerate top window):
+    // their lists are cut into segments of heavy_th entries, one thread per segment, partials combined
+    // by one wavefront per bucket.  They take rank "length 0" in perm[] so the main kernel skips them.
+    uint32_t heavy_th;
+    uint32_t heavy_cap;     // capacity of heavy_tasks / heavy_buckets (entries)
+    uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
+    uint2 *heavy_tasks;     // [heavy_cap] (bucket id, segment index)
+    uint4 *heavy_buckets;   // [heavy_cap] (bucket id, first task, segments, -)
 };
+__device__ __forceinline__ uint32_t size_bin(uint32_t c, uint32_t heavy_th) {
+    return c > heavy_th ? 0u : min(c, (uint32_t)SIZE_BINS - 1u);
+}
 
 template <bool PLACE>
 __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t nb) {
@@ -189,7 +200,23 @@ __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__rest
         if (2 * t < nloc) B.bucket_off[flat0 + 2 * t] = ex;
         if (2 * t + 1 < nloc) B.bucket_off[flat0 + 2 * t + 1] = ex + c0;
         // size ranking: local rank inside this workgroup's share of each length bin ...
-        const uint32_t b0 = min(c0, (uint32_t)SIZE_BINS - 1u), b1 = min(c1, (uint32_t)SIZE_BINS - 1u);
+        const uint32_t b0 = size_bin(c0, B.heavy_th), b1 = size_bin(c1, B.heavy_th);
+        // heavy buckets: register the bucket and one task per heavy_th-entry segment of its list
+        {
+            const uint32_t cc[2] = {c0, c1};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (cc[q] > B.heavy_th && 2 * t + q < nloc) {
+                    const uint32_t nseg = (cc[q] + B.heavy_th - 1) / B.heavy_th;
+                    const uint32_t tpos = atomicAdd(&B.heavy_ctr[0], nseg);
+                    const uint32_t hb = atomicAdd(&B.heavy_ctr[1], 1u);
+                    if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) {  // capacity is sized so this always holds
+                        B.heavy_buckets[hb] = make_uint4((uint32_t)(flat0 + 2 * t + q), tpos, nseg, 0u);
+                        for (uint32_t k = 0; k < nseg; k++) B.heavy_tasks[tpos + k] = make_uint2((uint32_t)(flat0 + 2 * t + q), k);
+                    }
+                }
+            }
+        }
         uint32_t r0 = 0, r1 = 0;
         if (2 * t < nloc) r0 = atomicAdd(&hist[b0], 1u);
         if (2 * t + 1 < nloc) r1 = atomicAdd(&hist[b1], 1u);
@@ -226,11 +253,11 @@ __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__rest
         const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
         if (2 * t < nloc) {
             counts[flat0 + 2 * t] = c0;
-            atomicAdd(&hist[min(c0, (uint32_t)SIZE_BINS - 1u)], 1u);
+            atomicAdd(&hist[size_bin(c0, B.heavy_th)], 1u);
         }
         if (2 * t + 1 < nloc) {
             counts[flat0 + 2 * t + 1] = c1;
-            atomicAdd(&hist[min(c1, (uint32_t)SIZE_BINS - 1u)], 1u);
+            atomicAdd(&hist[size_bin(c1, B.heavy_th)], 1u);
         }
         uint32_t total;
         (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);  // contains the barriers hist needs
@@ -257,6 +284,7 @@ __global__ __launch_bounds__(SIZE_BINS) void msm_scan_kernel(SortBufs B, uint32_
     B.size_base[bin] = hx;
     B.size_hist[bin] = 0;
     B.size_cursor[bin] = 0;
+    if (t < 2) B.heavy_ctr[t] = 0;
 }
 
 // ------------------------------------------------------------------------------ accumulate
@@ -264,19 +292,11 @@ __global__ __launch_bounds__(SIZE_BINS) void msm_scan_kernel(SortBufs B, uint32_
 // length (perm[]): the 64 lanes of a wavefront own lists of (nearly) equal length, wavefronts retire
 // independently and the longest lists start first.  Each thread adds its points in XYZZ mixed
 // coordinates (8M+2S per point), the next (index, point) pair being fetched under the current add.
+// Sum of the points listed in lst[0..len): XYZZ mixed additions with the next entry prefetched.
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
-                                                             const uint32_t *__restrict__ counts,
-                                                             const uint32_t *__restrict__ bucket_off,
-                                                             const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
-                                                             uint32_t nbuckets) {
-    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= nbuckets) return;
-    const uint32_t b = perm[r];
-    const uint32_t len = counts[b];
+__device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ lst, uint32_t len) {
     Xyzz<F> acc = Xyzz<F>::inf();
     if (len) {
-        const uint32_t *lst = sorted + bucket_off[b];
         uint32_t e = lst[0];
         PackedAffine<F> pk = pts[e & 0x7fffffffu];
         for (uint32_t k = 1; k <= len; k++) {
@@ -293,7 +313,62 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumul
             pk = pk2;
         }
     }
-    buckets[b] = acc;
+    return acc;
+}
+
+template <class F>
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+                                                             const uint32_t *__restrict__ counts,
+                                                             const uint32_t *__restrict__ bucket_off,
+                                                             const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
+                                                             uint32_t nbuckets, uint32_t heavy_th) {
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= nbuckets) return;
+    const uint32_t b = perm[r];
+    const uint32_t len = counts[b];
+    if (len > heavy_th) return;  // summed by the heavy kernels
+    buckets[b] = sum_list(pts, sorted + bucket_off[b], len);
+}
+
+// Heavy buckets, stage 1: one thread per (bucket, segment) task -> partial sums.
+template <class F>
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_heavy_segments_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B,
+                                                                                            Xyzz<F> *__restrict__ partial) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= min(B.heavy_ctr[0], B.heavy_cap)) return;
+    const uint2 task = B.heavy_tasks[t];
+    const uint32_t len = B.counts[task.x], lo = task.y * B.heavy_th;
+    partial[t] = sum_list(pts, B.sorted + B.bucket_off[task.x] + lo, min(B.heavy_th, len - lo));
+}
+
+template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
+    Xyzz<F> r;
+    constexpr int NW = sizeof(Xyzz<F>) / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
+    return r;
+}
+// Heavy buckets, stage 2: one wavefront per bucket; lanes sum the partials serially with stride 64,
+// then a wavefront __shfl tree leaves the bucket sum in lane 0.
+template <class F>
+__global__ __launch_bounds__(64) void msm_heavy_combine_kernel(SortBufs B, const Xyzz<F> *__restrict__ partial, Xyzz<F> *__restrict__ buckets) {
+    const uint32_t nheavy = min(B.heavy_ctr[1], B.heavy_cap), lane = threadIdx.x;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint4 hb = B.heavy_buckets[h];
+        Xyzz<F> acc = Xyzz<F>::inf();
+        for (uint32_t k = lane; k < hb.z; k += 64) {
+            const Xyzz<F> v = partial[hb.y + k];
+            xyzz_add(acc, v);
+        }
+#pragma unroll 1
+        for (int d = 32; d >= 1; d >>= 1) {
+            const Xyzz<F> o = shfl_down_xyzz(acc, d);
+            xyzz_add(acc, o);
+        }
+        if (lane == 0) buckets[hb.x] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------ reduce
@@ -374,15 +449,20 @@ __global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz
 
 // ------------------------------------------------------------------------------ host side
 static int pick_window_bits(size_t n) {
-    if (n <= (1u << 9)) return 8;
-    if (n <= (1u << 14)) return 12;
+    // widths whose top window is not degenerate (255 = W*c - slack: the top window of c = 13 / 15 / 16
+    // still holds 7 / 14 / 14 scalar bits; c = 9, 11, 12, 14 would leave it 1-2 bits = 1-3 giant buckets)
+    if (n <= (1u << 8)) return 8;
+    if (n <= (1u << 11)) return 10;
+    if (n <= (1u << 14)) return 13;
+    if (n <= (1u << 17)) return 15;
     return 16;
 }
 
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, size_bins, perm, arena, out;
+    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
+    uint32_t heavy_cap = 0;
     PinnedBuf h_out;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
 
@@ -393,7 +473,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         pts_m.alloc(max_n * sizeof(PackedAffine<F>));
         // digits: worst case over the window choices available to n <= max_n
         size_t dig = 0, ar = 0, outn = 0;
-        const int cs[3] = {8, 12, 16};
+        const int cs[5] = {8, 10, 13, 15, 16};
         for (int c : cs) {
             if (c > pick_window_bits(max_n)) continue;
             size_t W = (255 + c - 1) / c, nb = (size_t)1 << (c - 1);
@@ -407,8 +487,13 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         bucket_off.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         group_tot.alloc(256 * sizeof(uint32_t));
         group_base.alloc(256 * sizeof(uint32_t));
-        size_bins.alloc(3 * SIZE_BINS * sizeof(uint32_t));  // size_hist | size_base | size_cursor
-        ZK_HIP(hipMemset(size_bins.p, 0, 3 * SIZE_BINS * sizeof(uint32_t)));
+        size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
+        ZK_HIP(hipMemset(size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
+        // heavy-bucket scratch: tasks <= 2*n*W/heavy_th with heavy_th = max(32, 8n/nb), i.e. <= W*nb/2 (with room)
+        heavy_cap = (uint32_t)(ar / sizeof(Xyzz<F>) / 2 + 64);
+        heavy_tasks.alloc((size_t)heavy_cap * sizeof(uint2));
+        heavy_buckets.alloc((size_t)heavy_cap * sizeof(uint4));
+        heavy_partial.alloc((size_t)heavy_cap * sizeof(Xyzz<F>));
         perm.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         arena.alloc(ar);
         out.alloc(outn);
@@ -445,6 +530,11 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.size_base = B.size_hist + SIZE_BINS;
         B.size_cursor = B.size_hist + 2 * SIZE_BINS;
         B.perm = perm.as<uint32_t>();
+        B.heavy_th = std::max<uint32_t>(32, 8 * (n_pad / nb));
+        B.heavy_cap = heavy_cap;
+        B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
+        B.heavy_tasks = heavy_tasks.as<uint2>();
+        B.heavy_buckets = heavy_buckets.as<uint4>();
         hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
         hipLaunchKernelGGL((msm_scan_kernel<0>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
@@ -452,7 +542,12 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const uint32_t nbuckets = W * nb;
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(),
                            sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), perm.as<uint32_t>(),
-                           arena.as<Xyzz<F>>(), nbuckets);
+                           arena.as<Xyzz<F>>(), nbuckets, B.heavy_th);
+        // heavy buckets (normally none): the grids cover the worst case and exit on the device-side counters
+        const uint32_t max_tasks = std::min<uint32_t>(heavy_cap, 2 * (uint32_t)(((size_t)n_pad * W) / B.heavy_th) + 64);
+        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3((max_tasks + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(), B,
+                           heavy_partial.as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(std::min<uint32_t>(max_tasks, 1024)), dim3(64), 0, st, B, heavy_partial.as<Xyzz<F>>(), arena.as<Xyzz<F>>());
     }
 
     // Enqueues the GPU pipeline and reads the window/level sums back; returns the XYZZ result.
@@ -466,7 +561,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(0, st);
         switch (c) {
             case 8: launch_prepare<8>(sc, pt, (uint32_t)n, n_pad, st); break;
-            case 12: launch_prepare<12>(sc, pt, (uint32_t)n, n_pad, st); break;
+            case 10: launch_prepare<10>(sc, pt, (uint32_t)n, n_pad, st); break;
+            case 13: launch_prepare<13>(sc, pt, (uint32_t)n, n_pad, st); break;
+            case 15: launch_prepare<15>(sc, pt, (uint32_t)n, n_pad, st); break;
             default: launch_prepare<16>(sc, pt, (uint32_t)n, n_pad, st); break;
         }
         mark(1, st);

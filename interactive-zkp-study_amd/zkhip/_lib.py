@@ -67,6 +67,13 @@ def load():
             raise RuntimeError(
                 "libzkhip.so not found at %s -- build it with `make -C interactive-zkp-study_amd/csrc` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64; when torch shares the process (device
+        # buffers, streams, torch.distributed) it has to be loaded FIRST so that both resolve to one HIP
+        # runtime -- a second runtime initialised later reports "No HIP GPUs are available".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(lib, name)

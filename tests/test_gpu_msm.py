@@ -33,8 +33,8 @@ def msm_g2(S, Pts):
     return out
 
 
-# sizes straddle the window-width switches (c = 8 | 12 | 16 at n = 512 / 16384) and block edges
-@pytest.mark.parametrize("n", [1, 2, 3, 17, 255, 256, 257, 512, 513, 1000, 4095, 4096, 4097, 16384, 16385, 40000])
+# sizes straddle the window-width switches (c = 8 | 10 | 13 | 15 | 16 at n = 2^8 / 2^11 / 2^14 / 2^17) and block edges
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 255, 256, 257, 512, 513, 1000, 2048, 2049, 4095, 4096, 4097, 16384, 16385, 40000])
 def test_g1_msm_bit_exact_vs_oracle(n):
     rng = np.random.default_rng(1000 + n)
     S = rand_fr_limbs(rng, n)
@@ -153,6 +153,20 @@ def test_g1_msm_2pow16_bit_exact():
     S = rand_fr_limbs(rng, n)
     Pts, _ = rand_g1_limbs(rng, n)
     assert np.array_equal(msm_g1(S, Pts), co.g1_msm_arr(S, Pts))
+
+
+@pytest.mark.parametrize("n", [131072, 131073, 300001])
+def test_g1_msm_closed_form_across_c16_switch(n):
+    """P_i = k_i*G1 (generated on the GPU, spot-checked against the oracle): MSM = (sum s_i k_i) * G1."""
+    from bench import random_scalars
+    rng = np.random.default_rng(n)
+    S, K = random_scalars(rng, n), random_scalars(rng, n)
+    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+    Pts = np.zeros((n, 8), dtype=np.uint64)
+    _lib.check(_lib.load().zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(K), n, _lib.ptr(Pts)))
+    idx = [0, n // 2, n - 1]
+    assert np.array_equal(Pts[idx], co.g1_fixed_base_arr(o.G1, K[idx]))
+    assert co.g1_from_arr(msm_g1(S, Pts))[0] == co.g1_mul(o.G1, co.fr_dot_arr(S, K))
 
 
 def test_g1_msm_2pow20_closed_form_and_linearity():
