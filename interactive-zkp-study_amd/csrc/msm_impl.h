@@ -63,50 +63,67 @@ template <class F> __device__ __forceinline__ F ld_canonical(const uint32_t *p) 
 }
 
 // ------------------------------------------------------------------------------ prepare
-// digits[w * n_pad + i] = signed digit d in [-2^(C-1), 2^(C-1)-1] of scalar i for window w.
+// digits[w * n_pad + i] = signed digit d in [-2^(C-1), 2^(C-1)-1] of scalar i for window w, and
+// group_total[w * G + g] += number of non-zero digits of window w whose bucket |d|-1 falls into the
+// g-th group of SORT_BPG buckets (per-workgroup LDS histogram, one global atomic per non-empty cell).
+constexpr int PREP_NT = 1024;
+constexpr int SORT_BPG = 2048;      // buckets owned by one sort workgroup
+constexpr int SORT_BPG_LOG = 11;
+
 template <class F, int C>
-__global__ __launch_bounds__(256) void msm_prepare_kernel(const uint32_t *__restrict__ scalars,
-                                                          const uint32_t *__restrict__ points,
-                                                          PackedAffine<F> *__restrict__ pts_m,
-                                                          int16_t *__restrict__ digits, uint32_t n, uint32_t n_pad) {
+__global__ __launch_bounds__(PREP_NT) void msm_prepare_kernel(const uint32_t *__restrict__ scalars,
+                                                              const uint32_t *__restrict__ points,
+                                                              PackedAffine<F> *__restrict__ pts_m,
+                                                              int16_t *__restrict__ digits, uint32_t *__restrict__ group_total,
+                                                              uint32_t n, uint32_t n_pad) {
     constexpr int W = (255 + C - 1) / C;
     constexpr int PW = F::CANON_WORDS;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_pad) return;
-    if (i >= n) {
+    constexpr int G = ((1 << (C - 1)) + SORT_BPG - 1) / SORT_BPG;
+    __shared__ uint32_t hist[W * G];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t; k < W * G; k += PREP_NT) hist[k] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * PREP_NT + t;
+    if (i < n_pad && i >= n) {
 #pragma unroll
         for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
-        return;
-    }
-    const F x = ld_canonical<F>(points + (size_t)i * 2 * PW);
-    const F y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
-    const bool inf = x.is_zero() && y.is_zero();  // canonical inputs: infinity is the all-zero encoding
-    pts_m[i] = pack_affine(Affine<F>{fe_to_mont(x), fe_to_mont(y)});
+    } else if (i < n) {
+        const F x = ld_canonical<F>(points + (size_t)i * 2 * PW);
+        const F y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
+        const bool inf = x.is_zero() && y.is_zero();  // canonical inputs: infinity is the all-zero encoding
+        pts_m[i] = pack_affine(Affine<F>{fe_to_mont(x), fe_to_mont(y)});
 
-    uint32_t s[8];
-    ld_words<8>(scalars + (size_t)i * 8, s);
-    uint32_t carry = 0;
+        uint32_t s[8];
+        ld_words<8>(scalars + (size_t)i * 8, s);
+        uint32_t carry = 0;
 #pragma unroll
-    for (int w = 0; w < W; w++) {
-        constexpr uint32_t mask = (1u << C) - 1u;
-        const int off = w * C, word = off >> 5, sh = off & 31;
-        uint32_t raw = 0;
-        if (word < 8) {
-            raw = s[word] >> sh;
-            if (sh + C > 32 && word + 1 < 8) raw |= s[word + 1] << (32 - sh);
+        for (int w = 0; w < W; w++) {
+            constexpr uint32_t mask = (1u << C) - 1u;
+            const int off = w * C, word = off >> 5, sh = off & 31;
+            uint32_t raw = 0;
+            if (word < 8) {
+                raw = s[word] >> sh;
+                if (sh + C > 32 && word + 1 < 8) raw |= s[word + 1] << (32 - sh);
+            }
+            raw &= mask;
+            uint32_t v = raw + carry;
+            int d;
+            if (v >= (1u << (C - 1))) {
+                d = (int)v - (1 << C);
+                carry = 1;
+            } else {
+                d = (int)v;
+                carry = 0;
+            }
+            if (inf) d = 0;
+            digits[(size_t)w * n_pad + i] = (int16_t)d;
+            if (d != 0) atomicAdd(&hist[w * G + (((uint32_t)(d < 0 ? -d : d) - 1u) >> SORT_BPG_LOG)], 1u);
         }
-        raw &= mask;
-        uint32_t v = raw + carry;
-        int d;
-        if (v >= (1u << (C - 1))) {
-            d = (int)v - (1 << C);
-            carry = 1;
-        } else {
-            d = (int)v;
-            carry = 0;
-        }
-        if (inf) d = 0;
-        digits[(size_t)w * n_pad + i] = (int16_t)d;
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < W * G; k += PREP_NT) {
+        const uint32_t h = hist[k];
+        if (h) atomicAdd(&group_total[k], h);
     }
 }
 
@@ -149,14 +166,17 @@ template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint3
 //   size_hist[]; PLACE reserves one span per (workgroup, length) with a single global atomic and
 //   writes the bucket ids into perm[], so the accumulate kernel's wavefronts get equal-length lists.
 constexpr int SORT_NT = 1024;
-constexpr int SORT_BPG = 2048;
 constexpr int SIZE_BINS = 1024;  // list lengths >= SIZE_BINS-1 share the top bin
 
 struct SortBufs {
     uint32_t *counts;       // [W*nb]   list length of every bucket
     uint32_t *bucket_off;   // [W*nb]   start of every bucket's list inside sorted[]
     uint32_t *group_base;   // [groups] exclusive scan of group_total
-    uint32_t *group_total;  // [groups] entries per (window, bucket group)
+    uint32_t *group_total;  // [groups] entries per (window, bucket group); accumulated by prepare, zeroed by the scan kernel
+    uint32_t *group_cnt;    // [groups] copy of group_total for the sort passes
+    uint32_t *seg_cursor;   // [groups] partition write cursors (zeroed by the scan kernel)
+    uint32_t *e_idx;        // [W*n]    partitioned entries: point index | sign << 31, grouped by (window, bucket group)
+    uint16_t *e_loc;        // [W*n]    partitioned entries: bucket index inside the group
     uint32_t *sorted;       // [W*n]    point index | sign << 31
     uint32_t *size_hist;    // [SIZE_BINS] buckets per list length (zeroed by the scan kernel after use)
     uint32_t *size_base;    // [SIZE_BINS] first rank of each length, longest first
@@ -175,8 +195,40 @@ __device__ __forceinline__ uint32_t size_bin(uint32_t c, uint32_t heavy_th) {
     return c > heavy_th ? 0u : min(c, (uint32_t)SIZE_BINS - 1u);
 }
 
+// Coarse radix partition: every (window, point) entry goes to the segment of its (window, bucket group);
+// a workgroup reserves one contiguous span per segment (LDS histogram + one global atomic per cell) so
+// the sort passes below read exactly their own entries instead of filtering the whole digit row.
+template <int DUMMY>
+__global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t W,
+                                                                uint32_t G) {
+    __shared__ uint32_t cell[512];  // W * G <= 256
+    const uint32_t t = threadIdx.x, ncell = W * G;
+    for (uint32_t k = t; k < ncell; k += PREP_NT) cell[k] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * PREP_NT + t;
+    for (uint32_t w = 0; w < W; w++) {
+        const int d = digits[(size_t)w * n_pad + i];
+        if (d != 0) atomicAdd(&cell[w * G + (((uint32_t)(d < 0 ? -d : d) - 1u) >> SORT_BPG_LOG)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < ncell; k += PREP_NT) {
+        const uint32_t h = cell[k];
+        cell[k] = B.group_base[k] + (h ? atomicAdd(&B.seg_cursor[k], h) : 0u);
+    }
+    __syncthreads();
+    for (uint32_t w = 0; w < W; w++) {
+        const int d = digits[(size_t)w * n_pad + i];
+        if (d != 0) {
+            const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u;
+            const uint32_t pos = atomicAdd(&cell[w * G + (j >> SORT_BPG_LOG)], 1u);
+            B.e_idx[pos] = i | (d < 0 ? 0x80000000u : 0u);
+            B.e_loc[pos] = (uint16_t)(j & (SORT_BPG - 1));
+        }
+    }
+}
+
 template <bool PLACE>
-__global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t nb) {
+__global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(SortBufs B, uint32_t nb) {
     __shared__ uint32_t cnt[SORT_BPG];
     __shared__ uint32_t hist[SIZE_BINS];
     __shared__ uint32_t wave_tot[SORT_NT / 64 + 1];
@@ -231,22 +283,12 @@ __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__rest
         if (2 * t + 1 < nloc) B.perm[hist[b1] + r1] = (uint32_t)(flat0 + 2 * t + 1);
     }
     __syncthreads();
-    const uint4 *dv = reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad);
-    const uint32_t nvec = n_pad >> 3;
-    for (uint32_t v = t; v < nvec; v += SORT_NT) {
-        const uint4 q = dv[v];
-        const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int d = (int)(int16_t)((wd[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
-            if (d != 0) {
-                const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u - base;
-                if (j < nloc) {
-                    const uint32_t pos = atomicAdd(&cnt[j], 1u);
-                    if (PLACE) sorted[pos] = (v * 8 + k) | (d < 0 ? 0x80000000u : 0u);
-                }
-            }
-        }
+    const uint32_t seg0 = B.group_base[w * G + g], seg_n = B.group_cnt[w * G + g];
+    const uint16_t *__restrict__ loc = B.e_loc + seg0;
+    const uint32_t *__restrict__ idx = B.e_idx + seg0;
+    for (uint32_t v = t; v < seg_n; v += SORT_NT) {
+        const uint32_t pos = atomicAdd(&cnt[loc[v]], 1u);
+        if (PLACE) sorted[pos] = idx[v];
     }
     if (!PLACE) {
         __syncthreads();
@@ -260,31 +302,39 @@ __global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(const int16_t *__rest
             atomicAdd(&hist[size_bin(c1, B.heavy_th)], 1u);
         }
         uint32_t total;
-        (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);  // contains the barriers hist needs
-        if (t == 0) B.group_total[w * G + g] = total;
+        (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);  // (its barriers also order the hist atomics)
         const uint32_t h = hist[t];
         if (h) atomicAdd(&B.size_hist[t], h);
     }
 }
 
-// One workgroup: exclusive scan of the (<= 256) group totals, and of the list-length histogram in
-// DEcreasing length order (rank 0 = longest lists).  Leaves size_hist / size_cursor zeroed for the
-// next run (they start zeroed at plan creation).
-template <int DUMMY>
+// One workgroup.  SIZES == false (after prepare): exclusive scan of the (<= 256) segment totals ->
+// group_base / group_cnt.  SIZES == true (after the COUNT pass): exclusive scan of the list-length
+// histogram in DEcreasing length order (rank 0 = longest lists).  Each leaves the counters it consumed
+// zeroed for the next run (they start zeroed at plan creation).
+template <bool SIZES>
 __global__ __launch_bounds__(SIZE_BINS) void msm_scan_kernel(SortBufs B, uint32_t ngroups) {
     __shared__ uint32_t wave_tot[SIZE_BINS / 64 + 1];
     const uint32_t t = threadIdx.x;
     uint32_t total;
-    const uint32_t v = t < ngroups ? B.group_total[t] : 0u;
-    const uint32_t ex = block_exclusive_scan<SIZE_BINS>(v, wave_tot, &total);
-    if (t < ngroups) B.group_base[t] = ex;
-    const uint32_t bin = SIZE_BINS - 1u - t;  // thread 0 takes the longest lists
-    const uint32_t hv = B.size_hist[bin];
-    const uint32_t hx = block_exclusive_scan<SIZE_BINS>(hv, wave_tot, &total);
-    B.size_base[bin] = hx;
-    B.size_hist[bin] = 0;
-    B.size_cursor[bin] = 0;
-    if (t < 2) B.heavy_ctr[t] = 0;
+    if (!SIZES) {
+        const uint32_t v = t < ngroups ? B.group_total[t] : 0u;
+        const uint32_t ex = block_exclusive_scan<SIZE_BINS>(v, wave_tot, &total);
+        if (t < ngroups) {
+            B.group_base[t] = ex;
+            B.group_cnt[t] = v;
+            B.group_total[t] = 0;
+            B.seg_cursor[t] = 0;
+        }
+    } else {
+        const uint32_t bin = SIZE_BINS - 1u - t;  // thread 0 takes the longest lists
+        const uint32_t hv = B.size_hist[bin];
+        const uint32_t hx = block_exclusive_scan<SIZE_BINS>(hv, wave_tot, &total);
+        B.size_base[bin] = hx;
+        B.size_hist[bin] = 0;
+        B.size_cursor[bin] = 0;
+        if (t < 2) B.heavy_ctr[t] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------ accumulate
@@ -461,7 +511,7 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, counts, bucket_off, group_tot, group_base, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
+    DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, group_tot, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
     uint32_t heavy_cap = 0;
     PinnedBuf h_out;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
@@ -485,8 +535,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         sorted.alloc(dig * 2);  // one 4-byte entry per (window, point)
         counts.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         bucket_off.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
-        group_tot.alloc(256 * sizeof(uint32_t));
-        group_base.alloc(256 * sizeof(uint32_t));
+        e_idx.alloc(dig * 2);
+        e_loc.alloc(dig);
+        group_tot.alloc(4 * 256 * sizeof(uint32_t));  // group_total | group_base | group_cnt | seg_cursor
+        ZK_HIP(hipMemset(group_tot.p, 0, 4 * 256 * sizeof(uint32_t)));
         size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
         ZK_HIP(hipMemset(size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
         // heavy-bucket scratch: tasks <= 2*n*W/heavy_th with heavy_th = max(32, 8n/nb), i.e. <= W*nb/2 (with room)
@@ -513,8 +565,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     int window_bits(size_t n) const override { return pick_window_bits(n); }
 
     template <int C> void launch_prepare(const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad, hipStream_t st) {
-        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / 256), dim3(256), 0, st, sc, pt, pts_m.as<PackedAffine<F>>(),
-                           digits.as<int16_t>(), n, n_pad);
+        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / PREP_NT), dim3(PREP_NT), 0, st, sc, pt, pts_m.as<PackedAffine<F>>(),
+                           digits.as<int16_t>(), group_tot.as<uint32_t>(), n, n_pad);
     }
     void launch_sort_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
         const uint32_t G = (nb + SORT_BPG - 1) / SORT_BPG;
@@ -523,8 +575,12 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         SortBufs B;
         B.counts = counts.as<uint32_t>();
         B.bucket_off = bucket_off.as<uint32_t>();
-        B.group_base = group_base.as<uint32_t>();
         B.group_total = group_tot.as<uint32_t>();
+        B.group_base = B.group_total + 256;
+        B.group_cnt = B.group_total + 512;
+        B.seg_cursor = B.group_total + 768;
+        B.e_idx = e_idx.as<uint32_t>();
+        B.e_loc = e_loc.as<uint16_t>();
         B.sorted = sorted.as<uint32_t>();
         B.size_hist = size_bins.as<uint32_t>();
         B.size_base = B.size_hist + SIZE_BINS;
@@ -535,9 +591,11 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
         B.heavy_tasks = heavy_tasks.as<uint2>();
         B.heavy_buckets = heavy_buckets.as<uint4>();
-        hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
-        hipLaunchKernelGGL((msm_scan_kernel<0>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
-        hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, digits.as<int16_t>(), B, n_pad, nb);
+        hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
+        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / PREP_NT), dim3(PREP_NT), 0, st, digits.as<int16_t>(), B, n_pad, W, G);
+        hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, B, nb);
+        hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
+        hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, B, nb);
         mark(2, st);
         const uint32_t nbuckets = W * nb;
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(),
