@@ -62,32 +62,108 @@ template <class F> __device__ __forceinline__ F ld_canonical(const uint32_t *p) 
     return fe_load_canonical(w, (F *)nullptr);
 }
 
-// ------------------------------------------------------------------------------ prepare
-// digits[w * n_pad + i] = signed digit d in [-2^(C-1), 2^(C-1)-1] of scalar i for window w, and
-// group_total[w * G + g] += number of non-zero digits of window w whose bucket |d|-1 falls into the
-// g-th group of SORT_BPG buckets (per-workgroup LDS histogram, one global atomic per non-empty cell).
-constexpr int PREP_NT = 1024;
-constexpr int SORT_BPG = 2048;      // buckets owned by one sort workgroup
-constexpr int SORT_BPG_LOG = 11;
+// ------------------------------------------------------------------------------ block scan
+// Exclusive scan of one value per thread over a block of NT threads (NT multiple of 64).
+// Returns the exclusive prefix; *total receives the block total (same in every thread).
+template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* NT/64+1 in LDS */, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= (uint32_t)d) inc += o;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) {
+        uint32_t t = wave_tot[k];
+        if ((uint32_t)k < wid) base += t;
+        tot += t;
+    }
+    *total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
 
+// ------------------------------------------------------------------------------ bucket sort
+// Two-level LDS-staged counting sort of the (window, bucket) -> point-index lists.
+//
+//   cells      a cell = SEG_BUCKETS (256) consecutive buckets of one window; <= 2048 cells.
+//   prepare    (above all) also histograms the digits per cell: LDS histogram per 4096-point
+//              workgroup, one global atomic per non-empty cell.
+//   partition  coarse radix pass: every (window, point) entry is written to its cell's segment
+//              (index | sign << 31 in e_idx, bucket-in-cell byte in e_loc); a workgroup reserves one
+//              contiguous span per cell, so writes are short runs, never single scattered words.
+//   segsort    one workgroup per cell: counts its 256 buckets (-> counts[], bucket_off[]), then sorts
+//              the segment chunk by chunk entirely in LDS (LDS-atomic ranks, block scan, staging
+//              buffer) and writes each chunk out as per-bucket runs -- coalesced reads, run-coalesced
+//              writes, no global atomics.
+//   rank       counting sort of the bucket ids by list length, longest first (perm[]), so that the
+//              accumulate kernel's wavefronts own equal-length lists; also registers heavy buckets.
+constexpr int SEG_BUCKETS = 256;
+constexpr int SEG_LOG = 8;
+constexpr int MAX_CELLS = 2048;
+constexpr int PREP_NT = 1024;
+constexpr int PREP_PPT = 4;  // points per thread in prepare / partition
+constexpr int SEG_NT = 256;
+constexpr int SEG_EPT = 16;  // entries per thread per chunk
+constexpr int SEG_CHUNK = SEG_NT * SEG_EPT;
+constexpr int SIZE_BINS = 1024;  // list lengths >= SIZE_BINS-1 share the top bin
+
+struct SortBufs {
+    uint32_t *counts;       // [W*nb]   list length of every bucket
+    uint32_t *bucket_off;   // [W*nb]   start of every bucket's list inside sorted[]
+    uint32_t *cell_total;   // [cells]  entries per cell; accumulated by prepare, zeroed by the scan kernel
+    uint32_t *cell_base;    // [cells]  exclusive scan of cell_total
+    uint32_t *cell_cnt;     // [cells]  copy of cell_total for the later passes
+    uint32_t *cell_cursor;  // [cells]  partition write cursors (zeroed by the scan kernel)
+    uint32_t *e_idx;        // [W*n]    partitioned entries: point index | sign << 31
+    uint8_t *e_loc;         // [W*n]    partitioned entries: bucket index inside the cell
+    uint32_t *sorted;       // [W*n]    entries grouped by bucket
+    uint32_t *size_hist;    // [SIZE_BINS] buckets per list length (zeroed by the scan kernel after use)
+    uint32_t *size_base;    // [SIZE_BINS] first rank of each length, longest first
+    uint32_t *size_cursor;  // [SIZE_BINS] running reservation (zeroed by the scan kernel)
+    uint32_t *perm;         // [W*nb]   bucket ids ordered by decreasing list length
+    // Heavy buckets (list longer than heavy_th: skewed / witness-like scalars, degenerate top window):
+    // their lists are cut into segments of heavy_th entries, one thread per segment, partials combined
+    // by one wavefront per bucket.  They take rank "length 0" in perm[] so the main kernel skips them.
+    uint32_t heavy_th;
+    uint32_t heavy_cap;     // capacity of heavy_tasks / heavy_buckets (entries)
+    uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
+    uint2 *heavy_tasks;     // [heavy_cap] (bucket id, segment index)
+    uint4 *heavy_buckets;   // [heavy_cap] (bucket id, first task, segments, -)
+};
+__device__ __forceinline__ uint32_t size_bin(uint32_t c, uint32_t heavy_th) {
+    return c > heavy_th ? 0u : min(c, (uint32_t)SIZE_BINS - 1u);
+}
+
+// ------------------------------------------------------------------------------ prepare
+// digits[w * n_pad + i] = signed digit d in [-2^(C-1), 2^(C-1)-1] of scalar i for window w;
+// cell_total[w * G + g] += number of non-zero digits of window w whose bucket |d|-1 lies in cell g.
 template <class F, int C>
 __global__ __launch_bounds__(PREP_NT) void msm_prepare_kernel(const uint32_t *__restrict__ scalars,
                                                               const uint32_t *__restrict__ points,
                                                               PackedAffine<F> *__restrict__ pts_m,
-                                                              int16_t *__restrict__ digits, uint32_t *__restrict__ group_total,
+                                                              int16_t *__restrict__ digits, uint32_t *__restrict__ cell_total,
                                                               uint32_t n, uint32_t n_pad) {
     constexpr int W = (255 + C - 1) / C;
     constexpr int PW = F::CANON_WORDS;
-    constexpr int G = ((1 << (C - 1)) + SORT_BPG - 1) / SORT_BPG;
+    constexpr int G = ((1 << (C - 1)) + SEG_BUCKETS - 1) / SEG_BUCKETS;
+    static_assert(W * G <= MAX_CELLS, "too many cells");
     __shared__ uint32_t hist[W * G];
     const uint32_t t = threadIdx.x;
     for (uint32_t k = t; k < W * G; k += PREP_NT) hist[k] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * PREP_NT + t;
-    if (i < n_pad && i >= n) {
+#pragma unroll 1
+    for (int rep = 0; rep < PREP_PPT; rep++) {
+        const uint32_t i = (blockIdx.x * PREP_PPT + rep) * PREP_NT + t;
+        if (i >= n) {  // padding (n_pad is a multiple of the workgroup's 4096 points)
 #pragma unroll
-        for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
-    } else if (i < n) {
+            for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
+            continue;
+        }
         const F x = ld_canonical<F>(points + (size_t)i * 2 * PW);
         const F y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
         const bool inf = x.is_zero() && y.is_zero();  // canonical inputs: infinity is the all-zero encoding
@@ -117,224 +193,225 @@ __global__ __launch_bounds__(PREP_NT) void msm_prepare_kernel(const uint32_t *__
             }
             if (inf) d = 0;
             digits[(size_t)w * n_pad + i] = (int16_t)d;
-            if (d != 0) atomicAdd(&hist[w * G + (((uint32_t)(d < 0 ? -d : d) - 1u) >> SORT_BPG_LOG)], 1u);
+            if (d != 0) atomicAdd(&hist[w * G + (((uint32_t)(d < 0 ? -d : d) - 1u) >> SEG_LOG)], 1u);
         }
     }
     __syncthreads();
     for (uint32_t k = t; k < W * G; k += PREP_NT) {
         const uint32_t h = hist[k];
-        if (h) atomicAdd(&group_total[k], h);
+        if (h) atomicAdd(&cell_total[k], h);
     }
 }
 
-// ------------------------------------------------------------------------------ block scan
-// Exclusive scan of one value per thread over a block of NT threads (NT multiple of 64).
-// Returns the exclusive prefix; *total receives the block total (same in every thread).
-template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* NT/64+1 in LDS */, uint32_t *total) {
-    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= (uint32_t)d) inc += o;
-    }
-    if (lane == 63) wave_tot[wid] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < NT / 64; k++) {
-        uint32_t t = wave_tot[k];
-        if ((uint32_t)k < wid) base += t;
-        tot += t;
-    }
-    *total = tot;
-    __syncthreads();
-    return base + inc - v;
-}
-
-// ------------------------------------------------------------------------------ bucket sort
-// Counting sort of the (window, bucket) -> point-index lists, staged through LDS counters.
-// grid = (ceil(nb / SORT_BPG), W); one workgroup owns SORT_BPG consecutive buckets of one window
-// and streams that window's digit row (L2-resident: a row is n*2 bytes and is shared by the
-// nb/SORT_BPG workgroups of the window).
-//   COUNT pass: LDS-atomic histogram -> counts[flat bucket], group_total[group]
-//   PLACE pass: counts -> exclusive offsets (block scan + group base), LDS-atomic cursors,
-//               entries (point index | sign << 31) written to sorted[] (each workgroup's output
-//               region is one contiguous, L2-resident span).
-//   Both passes also build the size ranking of the buckets (a counting sort of the bucket ids by
-//   list length, longest first): COUNT adds a per-workgroup LDS histogram of the lengths to
-//   size_hist[]; PLACE reserves one span per (workgroup, length) with a single global atomic and
-//   writes the bucket ids into perm[], so the accumulate kernel's wavefronts get equal-length lists.
-constexpr int SORT_NT = 1024;
-constexpr int SIZE_BINS = 1024;  // list lengths >= SIZE_BINS-1 share the top bin
-
-struct SortBufs {
-    uint32_t *counts;       // [W*nb]   list length of every bucket
-    uint32_t *bucket_off;   // [W*nb]   start of every bucket's list inside sorted[]
-    uint32_t *group_base;   // [groups] exclusive scan of group_total
-    uint32_t *group_total;  // [groups] entries per (window, bucket group); accumulated by prepare, zeroed by the scan kernel
-    uint32_t *group_cnt;    // [groups] copy of group_total for the sort passes
-    uint32_t *seg_cursor;   // [groups] partition write cursors (zeroed by the scan kernel)
-    uint32_t *e_idx;        // [W*n]    partitioned entries: point index | sign << 31, grouped by (window, bucket group)
-    uint16_t *e_loc;        // [W*n]    partitioned entries: bucket index inside the group
-    uint32_t *sorted;       // [W*n]    point index | sign << 31
-    uint32_t *size_hist;    // [SIZE_BINS] buckets per list length (zeroed by the scan kernel after use)
-    uint32_t *size_base;    // [SIZE_BINS] first rank of each length, longest first
-    uint32_t *size_cursor;  // [SIZE_BINS] running reservation (zeroed by the scan kernel)
-    uint32_t *perm;         // [W*nb]   bucket ids ordered by decreasing list length
-    // Heavy buckets (list longer than heavy_th: skewed / witness-like scalars, degenerate top window):
-    // their lists are cut into segments of heavy_th entries, one thread per segment, partials combined
-    // by one wavefront per bucket.  They take rank "length 0" in perm[] so the main kernel skips them.
-    uint32_t heavy_th;
-    uint32_t heavy_cap;     // capacity of heavy_tasks / heavy_buckets (entries)
-    uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
-    uint2 *heavy_tasks;     // [heavy_cap] (bucket id, segment index)
-    uint4 *heavy_buckets;   // [heavy_cap] (bucket id, first task, segments, -)
-};
-__device__ __forceinline__ uint32_t size_bin(uint32_t c, uint32_t heavy_th) {
-    return c > heavy_th ? 0u : min(c, (uint32_t)SIZE_BINS - 1u);
-}
-
-// Coarse radix partition: every (window, point) entry goes to the segment of its (window, bucket group);
-// a workgroup reserves one contiguous span per segment (LDS histogram + one global atomic per cell) so
-// the sort passes below read exactly their own entries instead of filtering the whole digit row.
-template <int DUMMY>
-__global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t W,
-                                                                uint32_t G) {
-    __shared__ uint32_t cell[512];  // W * G <= 256
-    const uint32_t t = threadIdx.x, ncell = W * G;
-    for (uint32_t k = t; k < ncell; k += PREP_NT) cell[k] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * PREP_NT + t;
-    for (uint32_t w = 0; w < W; w++) {
-        const int d = digits[(size_t)w * n_pad + i];
-        if (d != 0) atomicAdd(&cell[w * G + (((uint32_t)(d < 0 ? -d : d) - 1u) >> SORT_BPG_LOG)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = t; k < ncell; k += PREP_NT) {
-        const uint32_t h = cell[k];
-        cell[k] = B.group_base[k] + (h ? atomicAdd(&B.seg_cursor[k], h) : 0u);
-    }
-    __syncthreads();
-    for (uint32_t w = 0; w < W; w++) {
-        const int d = digits[(size_t)w * n_pad + i];
-        if (d != 0) {
-            const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u;
-            const uint32_t pos = atomicAdd(&cell[w * G + (j >> SORT_BPG_LOG)], 1u);
-            B.e_idx[pos] = i | (d < 0 ? 0x80000000u : 0u);
-            B.e_loc[pos] = (uint16_t)(j & (SORT_BPG - 1));
-        }
-    }
-}
-
-template <bool PLACE>
-__global__ __launch_bounds__(SORT_NT) void msm_sort_kernel(SortBufs B, uint32_t nb) {
-    __shared__ uint32_t cnt[SORT_BPG];
-    __shared__ uint32_t hist[SIZE_BINS];
-    __shared__ uint32_t wave_tot[SORT_NT / 64 + 1];
-    uint32_t *__restrict__ counts = B.counts;
-    uint32_t *__restrict__ sorted = B.sorted;
-    const uint32_t t = threadIdx.x, g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
-    const uint32_t base = g * SORT_BPG;
-    const uint32_t nloc = min((uint32_t)SORT_BPG, nb - base);
-    const size_t flat0 = (size_t)w * nb + base;
-    hist[t] = 0;  // SIZE_BINS == SORT_NT
-    if (!PLACE) {
-        cnt[2 * t] = 0;
-        cnt[2 * t + 1] = 0;
-    } else {
-        const uint32_t c0 = (2 * t < nloc) ? counts[flat0 + 2 * t] : 0u;
-        const uint32_t c1 = (2 * t + 1 < nloc) ? counts[flat0 + 2 * t + 1] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total) + B.group_base[w * G + g];
-        cnt[2 * t] = ex;
-        cnt[2 * t + 1] = ex + c0;
-        if (2 * t < nloc) B.bucket_off[flat0 + 2 * t] = ex;
-        if (2 * t + 1 < nloc) B.bucket_off[flat0 + 2 * t + 1] = ex + c0;
-        // size ranking: local rank inside this workgroup's share of each length bin ...
-        const uint32_t b0 = size_bin(c0, B.heavy_th), b1 = size_bin(c1, B.heavy_th);
-        // heavy buckets: register the bucket and one task per heavy_th-entry segment of its list
-        {
-            const uint32_t cc[2] = {c0, c1};
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                if (cc[q] > B.heavy_th && 2 * t + q < nloc) {
-                    const uint32_t nseg = (cc[q] + B.heavy_th - 1) / B.heavy_th;
-                    const uint32_t tpos = atomicAdd(&B.heavy_ctr[0], nseg);
-                    const uint32_t hb = atomicAdd(&B.heavy_ctr[1], 1u);
-                    if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) {  // capacity is sized so this always holds
-                        B.heavy_buckets[hb] = make_uint4((uint32_t)(flat0 + 2 * t + q), tpos, nseg, 0u);
-                        for (uint32_t k = 0; k < nseg; k++) B.heavy_tasks[tpos + k] = make_uint2((uint32_t)(flat0 + 2 * t + q), k);
-                    }
-                }
-            }
-        }
-        uint32_t r0 = 0, r1 = 0;
-        if (2 * t < nloc) r0 = atomicAdd(&hist[b0], 1u);
-        if (2 * t + 1 < nloc) r1 = atomicAdd(&hist[b1], 1u);
-        __syncthreads();
-        // ... one global reservation per non-empty bin ...
-        const uint32_t h = hist[t];
-        __syncthreads();
-        hist[t] = h ? B.size_base[t] + atomicAdd(&B.size_cursor[t], h) : 0u;
-        __syncthreads();
-        // ... and the bucket ids go to their ranks
-        if (2 * t < nloc) B.perm[hist[b0] + r0] = (uint32_t)(flat0 + 2 * t);
-        if (2 * t + 1 < nloc) B.perm[hist[b1] + r1] = (uint32_t)(flat0 + 2 * t + 1);
-    }
-    __syncthreads();
-    const uint32_t seg0 = B.group_base[w * G + g], seg_n = B.group_cnt[w * G + g];
-    const uint16_t *__restrict__ loc = B.e_loc + seg0;
-    const uint32_t *__restrict__ idx = B.e_idx + seg0;
-    for (uint32_t v = t; v < seg_n; v += SORT_NT) {
-        const uint32_t pos = atomicAdd(&cnt[loc[v]], 1u);
-        if (PLACE) sorted[pos] = idx[v];
-    }
-    if (!PLACE) {
-        __syncthreads();
-        const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
-        if (2 * t < nloc) {
-            counts[flat0 + 2 * t] = c0;
-            atomicAdd(&hist[size_bin(c0, B.heavy_th)], 1u);
-        }
-        if (2 * t + 1 < nloc) {
-            counts[flat0 + 2 * t + 1] = c1;
-            atomicAdd(&hist[size_bin(c1, B.heavy_th)], 1u);
-        }
-        uint32_t total;
-        (void)block_exclusive_scan<SORT_NT>(c0 + c1, wave_tot, &total);  // (its barriers also order the hist atomics)
-        const uint32_t h = hist[t];
-        if (h) atomicAdd(&B.size_hist[t], h);
-    }
-}
-
-// One workgroup.  SIZES == false (after prepare): exclusive scan of the (<= 256) segment totals ->
-// group_base / group_cnt.  SIZES == true (after the COUNT pass): exclusive scan of the list-length
-// histogram in DEcreasing length order (rank 0 = longest lists).  Each leaves the counters it consumed
-// zeroed for the next run (they start zeroed at plan creation).
+// One workgroup.  SIZES == false (after prepare): exclusive scan of the (<= 2048) cell totals ->
+// cell_base / cell_cnt.  SIZES == true (after segsort): exclusive scan of the list-length histogram
+// in DEcreasing length order (rank 0 = longest lists).  Each leaves the counters it consumed zeroed
+// for the next run (they start zeroed at plan creation).
 template <bool SIZES>
-__global__ __launch_bounds__(SIZE_BINS) void msm_scan_kernel(SortBufs B, uint32_t ngroups) {
-    __shared__ uint32_t wave_tot[SIZE_BINS / 64 + 1];
+__global__ __launch_bounds__(1024) void msm_scan_kernel(SortBufs B, uint32_t ncells) {
+    __shared__ uint32_t wave_tot[1024 / 64 + 1];
     const uint32_t t = threadIdx.x;
     uint32_t total;
     if (!SIZES) {
-        const uint32_t v = t < ngroups ? B.group_total[t] : 0u;
-        const uint32_t ex = block_exclusive_scan<SIZE_BINS>(v, wave_tot, &total);
-        if (t < ngroups) {
-            B.group_base[t] = ex;
-            B.group_cnt[t] = v;
-            B.group_total[t] = 0;
-            B.seg_cursor[t] = 0;
+        const uint32_t v0 = 2 * t < ncells ? B.cell_total[2 * t] : 0u;
+        const uint32_t v1 = 2 * t + 1 < ncells ? B.cell_total[2 * t + 1] : 0u;
+        const uint32_t ex = block_exclusive_scan<1024>(v0 + v1, wave_tot, &total);
+        if (2 * t < ncells) {
+            B.cell_base[2 * t] = ex;
+            B.cell_cnt[2 * t] = v0;
+            B.cell_total[2 * t] = 0;
+            B.cell_cursor[2 * t] = 0;
+        }
+        if (2 * t + 1 < ncells) {
+            B.cell_base[2 * t + 1] = ex + v0;
+            B.cell_cnt[2 * t + 1] = v1;
+            B.cell_total[2 * t + 1] = 0;
+            B.cell_cursor[2 * t + 1] = 0;
         }
     } else {
         const uint32_t bin = SIZE_BINS - 1u - t;  // thread 0 takes the longest lists
         const uint32_t hv = B.size_hist[bin];
-        const uint32_t hx = block_exclusive_scan<SIZE_BINS>(hv, wave_tot, &total);
+        const uint32_t hx = block_exclusive_scan<1024>(hv, wave_tot, &total);
         B.size_base[bin] = hx;
         B.size_hist[bin] = 0;
         B.size_cursor[bin] = 0;
         if (t < 2) B.heavy_ctr[t] = 0;
     }
+}
+
+// One workgroup = 4096 points.  Window by window: rank the 4096 digits by cell in LDS (LDS-atomic
+// ranks + block scan), reserve the cells' global spans (one atomic per non-empty cell), stage the
+// entries in cell order and write them out with consecutive lanes on consecutive addresses.
+template <int DUMMY>
+__global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t W,
+                                                                uint32_t G) {
+    constexpr int NE = PREP_NT * PREP_PPT;  // entries per window per workgroup
+    __shared__ uint32_t hist[128];           // G <= 128 cells per window: counts, then exclusive offsets
+    __shared__ uint32_t gpos[128];           // global position of this workgroup's span in every cell
+    __shared__ uint32_t wave_tot[PREP_NT / 64 + 1];
+    __shared__ uint32_t stage_idx[NE];
+    __shared__ uint8_t stage_loc[NE];
+    __shared__ uint8_t stage_cell[NE];
+    const uint32_t t = threadIdx.x;
+    const uint32_t i0 = blockIdx.x * NE + t;
+    for (uint32_t w = 0; w < W; w++) {
+        if (t < 128) hist[t] = 0;
+        __syncthreads();
+        uint32_t rk[PREP_PPT], jj[PREP_PPT];
+        int dd[PREP_PPT];
+#pragma unroll
+        for (int rep = 0; rep < PREP_PPT; rep++) {
+            dd[rep] = digits[(size_t)w * n_pad + i0 + rep * PREP_NT];
+            jj[rep] = (uint32_t)(dd[rep] < 0 ? -dd[rep] : dd[rep]) - 1u;
+            rk[rep] = dd[rep] != 0 ? atomicAdd(&hist[jj[rep] >> SEG_LOG], 1u) : 0u;
+        }
+        __syncthreads();
+        const uint32_t h = t < 128 ? hist[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<PREP_NT>(h, wave_tot, &total);
+        if (t < 128) {
+            hist[t] = ex;
+            gpos[t] = (h && t < G) ? B.cell_base[w * G + t] + atomicAdd(&B.cell_cursor[w * G + t], h) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rep = 0; rep < PREP_PPT; rep++) {
+            if (dd[rep] != 0) {
+                const uint32_t cellg = jj[rep] >> SEG_LOG;
+                const uint32_t p = hist[cellg] + rk[rep];
+                stage_idx[p] = (i0 + rep * PREP_NT) | (dd[rep] < 0 ? 0x80000000u : 0u);
+                stage_loc[p] = (uint8_t)(jj[rep] & (SEG_BUCKETS - 1));
+                stage_cell[p] = (uint8_t)cellg;
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = t; p < total; p += PREP_NT) {
+            const uint32_t cellg = stage_cell[p];
+            const uint32_t dst = gpos[cellg] + (p - hist[cellg]);
+            B.e_idx[dst] = stage_idx[p];
+            B.e_loc[dst] = stage_loc[p];
+        }
+        __syncthreads();
+    }
+}
+
+// grid = (G, W): one workgroup per cell.
+template <int DUMMY>
+__global__ __launch_bounds__(SEG_NT) void msm_segsort_kernel(SortBufs B, uint32_t nb) {
+    __shared__ uint32_t cur[SEG_BUCKETS];      // running global write position of every bucket
+    __shared__ uint32_t ch_hist[SEG_BUCKETS];  // per-chunk: entries per bucket, then exclusive offsets
+    __shared__ uint32_t hist[SIZE_BINS];
+    __shared__ uint32_t wave_tot[SEG_NT / 64 + 1];
+    __shared__ uint32_t stage_idx[SEG_CHUNK];
+    __shared__ uint8_t stage_loc[SEG_CHUNK];
+    const uint32_t t = threadIdx.x, g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+    const uint32_t cellid = w * G + g;
+    const uint32_t base = g * SEG_BUCKETS;
+    const uint32_t nloc = min((uint32_t)SEG_BUCKETS, nb - base);
+    const size_t flat0 = (size_t)w * nb + base;
+    const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
+    const uint8_t *__restrict__ loc = B.e_loc + seg0;
+    const uint32_t *__restrict__ idx = B.e_idx + seg0;
+    uint32_t *__restrict__ sorted = B.sorted;
+
+    // pass 1: bucket counts of the whole segment
+    cur[t] = 0;
+    for (uint32_t k = t; k < SIZE_BINS; k += SEG_NT) hist[k] = 0;
+    __syncthreads();
+    for (uint32_t v = t; v < seg_n; v += SEG_NT) atomicAdd(&cur[loc[v]], 1u);
+    __syncthreads();
+    const uint32_t c = cur[t];
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<SEG_NT>(c, wave_tot, &total);
+    if (t < nloc) {
+        B.counts[flat0 + t] = c;
+        B.bucket_off[flat0 + t] = seg0 + ex;
+        atomicAdd(&hist[size_bin(c, B.heavy_th)], 1u);
+    }
+    cur[t] = seg0 + ex;
+    __syncthreads();
+    for (uint32_t k = t; k < SIZE_BINS; k += SEG_NT) {
+        const uint32_t h = hist[k];
+        if (h) atomicAdd(&B.size_hist[k], h);
+    }
+
+    // pass 2: chunk-wise LDS counting sort, written out as per-bucket runs
+    for (uint32_t c0 = 0; c0 < seg_n; c0 += SEG_CHUNK) {
+        const uint32_t cn = min((uint32_t)SEG_CHUNK, seg_n - c0);
+        ch_hist[t] = 0;
+        __syncthreads();
+        uint32_t e_i[SEG_EPT], e_r[SEG_EPT];
+        uint8_t e_l[SEG_EPT];
+#pragma unroll
+        for (int k = 0; k < SEG_EPT; k++) {
+            const uint32_t v = k * SEG_NT + t;
+            if (v < cn) {
+                e_l[k] = loc[c0 + v];
+                e_i[k] = idx[c0 + v];
+                e_r[k] = atomicAdd(&ch_hist[e_l[k]], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t hc = ch_hist[t];
+        const uint32_t hx = block_exclusive_scan<SEG_NT>(hc, wave_tot, &total);
+        ch_hist[t] = hx;  // exclusive offsets inside the chunk
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SEG_EPT; k++) {
+            const uint32_t v = k * SEG_NT + t;
+            if (v < cn) {
+                const uint32_t p = ch_hist[e_l[k]] + e_r[k];
+                stage_idx[p] = e_i[k];
+                stage_loc[p] = e_l[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = t; p < cn; p += SEG_NT) {
+            const uint32_t l = stage_loc[p];
+            sorted[cur[l] + (p - ch_hist[l])] = stage_idx[p];
+        }
+        __syncthreads();
+        cur[t] += hc;
+        __syncthreads();
+    }
+}
+
+// grid covers the flattened bucket array, 2 buckets per thread: ranks the buckets by list length
+// (workgroup-local LDS histogram, one global reservation per non-empty length bin) and registers
+// heavy buckets with one task per heavy_th-entry segment of their list.
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbuckets) {
+    __shared__ uint32_t hist[SIZE_BINS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t b0i = (blockIdx.x * 1024 + t) * 2;
+    hist[t] = 0;
+    __syncthreads();
+    uint32_t cc[2], bin[2], r[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        cc[q] = (b0i + q < nbuckets) ? B.counts[b0i + q] : 0u;
+        bin[q] = size_bin(cc[q], B.heavy_th);
+        if (b0i + q < nbuckets) {
+            r[q] = atomicAdd(&hist[bin[q]], 1u);
+            if (cc[q] > B.heavy_th) {
+                const uint32_t nseg = (cc[q] + B.heavy_th - 1) / B.heavy_th;
+                const uint32_t tpos = atomicAdd(&B.heavy_ctr[0], nseg);
+                const uint32_t hb = atomicAdd(&B.heavy_ctr[1], 1u);
+                if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) {  // capacity is sized so this always holds
+                    B.heavy_buckets[hb] = make_uint4(b0i + q, tpos, nseg, 0u);
+                    for (uint32_t k = 0; k < nseg; k++) B.heavy_tasks[tpos + k] = make_uint2(b0i + q, k);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t h = hist[t];
+    __syncthreads();
+    hist[t] = h ? B.size_base[t] + atomicAdd(&B.size_cursor[t], h) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (b0i + q < nbuckets) B.perm[hist[bin[q]] + r[q]] = b0i + q;
 }
 
 // ------------------------------------------------------------------------------ accumulate
@@ -511,7 +588,7 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, group_tot, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
+    DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
     uint32_t heavy_cap = 0;
     PinnedBuf h_out;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
@@ -536,9 +613,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         counts.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         bucket_off.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         e_idx.alloc(dig * 2);
-        e_loc.alloc(dig);
-        group_tot.alloc(4 * 256 * sizeof(uint32_t));  // group_total | group_base | group_cnt | seg_cursor
-        ZK_HIP(hipMemset(group_tot.p, 0, 4 * 256 * sizeof(uint32_t)));
+        e_loc.alloc(dig / 2);
+        cells.alloc(4 * MAX_CELLS * sizeof(uint32_t));  // cell_total | cell_base | cell_cnt | cell_cursor
+        ZK_HIP(hipMemset(cells.p, 0, 4 * MAX_CELLS * sizeof(uint32_t)));
         size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
         ZK_HIP(hipMemset(size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
         // heavy-bucket scratch: tasks <= 2*n*W/heavy_th with heavy_th = max(32, 8n/nb), i.e. <= W*nb/2 (with room)
@@ -565,22 +642,21 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     int window_bits(size_t n) const override { return pick_window_bits(n); }
 
     template <int C> void launch_prepare(const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad, hipStream_t st) {
-        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / PREP_NT), dim3(PREP_NT), 0, st, sc, pt, pts_m.as<PackedAffine<F>>(),
-                           digits.as<int16_t>(), group_tot.as<uint32_t>(), n, n_pad);
+        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, sc, pt,
+                           pts_m.as<PackedAffine<F>>(), digits.as<int16_t>(), cells.as<uint32_t>(), n, n_pad);
     }
     void launch_sort_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
-        const uint32_t G = (nb + SORT_BPG - 1) / SORT_BPG;
-        if (G * W > 256) throw std::runtime_error("zk_msm: too many bucket groups");
-        const dim3 grid(G, W);
+        const uint32_t G = (nb + SEG_BUCKETS - 1) / SEG_BUCKETS;
+        if (G * W > MAX_CELLS) throw std::runtime_error("zk_msm: too many sort cells");
         SortBufs B;
         B.counts = counts.as<uint32_t>();
         B.bucket_off = bucket_off.as<uint32_t>();
-        B.group_total = group_tot.as<uint32_t>();
-        B.group_base = B.group_total + 256;
-        B.group_cnt = B.group_total + 512;
-        B.seg_cursor = B.group_total + 768;
+        B.cell_total = cells.as<uint32_t>();
+        B.cell_base = B.cell_total + MAX_CELLS;
+        B.cell_cnt = B.cell_total + 2 * MAX_CELLS;
+        B.cell_cursor = B.cell_total + 3 * MAX_CELLS;
         B.e_idx = e_idx.as<uint32_t>();
-        B.e_loc = e_loc.as<uint16_t>();
+        B.e_loc = e_loc.as<uint8_t>();
         B.sorted = sorted.as<uint32_t>();
         B.size_hist = size_bins.as<uint32_t>();
         B.size_base = B.size_hist + SIZE_BINS;
@@ -591,11 +667,12 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
         B.heavy_tasks = heavy_tasks.as<uint2>();
         B.heavy_buckets = heavy_buckets.as<uint4>();
-        hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
-        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / PREP_NT), dim3(PREP_NT), 0, st, digits.as<int16_t>(), B, n_pad, W, G);
-        hipLaunchKernelGGL((msm_sort_kernel<false>), grid, dim3(SORT_NT), 0, st, B, nb);
-        hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(SIZE_BINS), 0, st, B, G * W);
-        hipLaunchKernelGGL((msm_sort_kernel<true>), grid, dim3(SORT_NT), 0, st, B, nb);
+        const uint32_t nbuckets_all = W * nb;
+        hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, st, B, G * W);
+        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, digits.as<int16_t>(), B, n_pad, W, G);
+        hipLaunchKernelGGL((msm_segsort_kernel<0>), dim3(G, W), dim3(SEG_NT), 0, st, B, nb);
+        hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
+        hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((nbuckets_all + 2047) / 2048), dim3(1024), 0, st, B, nbuckets_all);
         mark(2, st);
         const uint32_t nbuckets = W * nb;
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(),
