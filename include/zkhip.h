@@ -128,6 +128,17 @@ int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t
  */
 int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scalar, size_t n, uint64_t *out);
 
+/* ------------------------------------------------------------------------------------------
+ * Pairings for the verifiers -- HOST code (a proof needs 2-4 pairings; never a GPU target).
+ * Replace py_ecc.bn128.pairing(Q, P) as used by zkp/groth16/verifying.py:17-40,
+ * zkp/plonk/field.py:118-138 and zkp/plonk/kzg.py:117-160.  Infinity inputs give the identity.
+ *   zk_pairing        e(P, Q) as 12 canonical F_p coefficients (4 limbs each) of
+ *                     F_p[w]/(w^12 - 18 w^6 + 82), the reference's FQ12 coefficient order.
+ *   zk_pairing_check  *out_is_one = [ prod_i e(P_i, Q_i) == 1 ]  (one shared final exponentiation).
+ */
+int zk_pairing(const uint64_t g1_xy[8], const uint64_t g2_xy[16], uint64_t out_fq12[48]);
+int zk_pairing_check(const uint64_t *g1_points /* n*8 */, const uint64_t *g2_points /* n*16 */, size_t n, int *out_is_one);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,8 @@ template <class F> static int fold_partials(const uint64_t *partials, size_t cou
     return ZK_OK;
 }
 
+int pairing_product(const uint64_t *g1_points, const uint64_t *g2_points, size_t n, uint64_t *out, int *is_one);  // pairing.hip
+
 }  // namespace zk
 
 using namespace zk;
@@ -236,6 +238,19 @@ int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scala
         if (group == ZK_GROUP_G1) return group_op_host<Fp>(op, p, q_or_scalar, n, out);
         if (group == ZK_GROUP_G2) return group_op_host<Fp2>(op, p, q_or_scalar, n, out);
         return invalid("zk_group_op: bad group");
+    });
+}
+
+int zk_pairing(const uint64_t g1_xy[8], const uint64_t g2_xy[16], uint64_t out_fq12[48]) {
+    return guarded([&] {
+        if (!g1_xy || !g2_xy || !out_fq12) return invalid("zk_pairing: null pointer");
+        return pairing_product(g1_xy, g2_xy, 1, out_fq12, nullptr);
+    });
+}
+int zk_pairing_check(const uint64_t *g1_points, const uint64_t *g2_points, size_t n, int *out_is_one) {
+    return guarded([&] {
+        if (!out_is_one || (n && (!g1_points || !g2_points))) return invalid("zk_pairing_check: null pointer");
+        return pairing_product(g1_points, g2_points, n, nullptr, out_is_one);
     });
 }
 

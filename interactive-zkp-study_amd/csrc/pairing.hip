@@ -1,0 +1,183 @@
+// pairing.hip -- HOST-side BN254 optimal-ate pairing for the verifiers (Groth16 verify: 4 pairings,
+// KZG opening check: 2 pairings).  A handful of pairings per proof is never a GPU target (SURVEY.md
+// section 8 f1); this file contains no device code.
+//
+// Replaces py_ecc.bn128.pairing as the reference uses it: zkp/groth16/verifying.py:17-40,
+// zkp/plonk/field.py:118-138, zkp/plonk/kzg.py:117-160.  The algorithm is py_ecc's
+// (bn128_pairing.py): Miller loop over ate_loop_count = 6u+2 with affine line functions, the two
+// Frobenius correction lines, final exponentiation by (p^12-1)/r -- computed here on the sextic
+// twist: G2 stays in F_p^2, F_p^12 = F_p^2[w]/(w^6 - xi), xi = 9 + i, and a line through twisted
+// points evaluates to the sparse element  -y_P + (m x_P) w + (y_1 - m x_1) w^3.
+// zk_pairing returns the value in py_ecc's basis (12 coefficients of F_p[w]/(w^12 - 18 w^6 + 82),
+// i -> w^6 - 9), so it can be compared with the reference's FQ12 objects coefficient by coefficient.
+#include <string.h>
+#include "common.h"
+#include "curve.h"
+#include "host_field.h"
+#include "msm.h"
+
+namespace zk {
+namespace {
+
+inline HFp2 fp2_conj(const HFp2 &a) { return HFp2{a.c0, fe_neg(a.c1)}; }
+inline HFp2 fp2_mul_xi(const HFp2 &a) {  // (a0 + a1 i)(9 + i)
+    HFp n0 = fe_dbl(fe_dbl(fe_dbl(a.c0))), n1 = fe_dbl(fe_dbl(fe_dbl(a.c1)));
+    n0 = fe_add(n0, a.c0);  // 9 a0
+    n1 = fe_add(n1, a.c1);  // 9 a1
+    return HFp2{fe_sub(n0, a.c1), fe_add(a.c0, n1)};
+}
+inline HFp2 fp2_from_fp(const HFp &a) { return HFp2{a, HFp::zero()}; }
+inline HFp2 fp2_mul_fp(const HFp2 &a, const HFp &k) { return HFp2{fe_mul(a.c0, k), fe_mul(a.c1, k)}; }
+
+struct Fp12 {
+    HFp2 c[6];  // sum c[k] w^k, w^6 = xi
+    static Fp12 one() {
+        Fp12 r;
+        for (auto &x : r.c) x = HFp2::zero();
+        r.c[0] = HFp2::one();
+        return r;
+    }
+    bool equals(const Fp12 &b) const {
+        for (int k = 0; k < 6; k++)
+            if (!c[k].equals(b.c[k])) return false;
+        return true;
+    }
+};
+
+Fp12 f12_mul(const Fp12 &a, const Fp12 &b) {
+    HFp2 t[11];
+    for (auto &x : t) x = HFp2::zero();
+    for (int i = 0; i < 6; i++) {
+        if (a.c[i].is_zero()) continue;
+        for (int j = 0; j < 6; j++) {
+            if (b.c[j].is_zero()) continue;
+            t[i + j] = fe_add(t[i + j], fe_mul(a.c[i], b.c[j]));
+        }
+    }
+    Fp12 r;
+    for (int k = 0; k < 6; k++) r.c[k] = k < 5 ? fe_add(t[k], fp2_mul_xi(t[k + 6])) : t[5];
+    return r;
+}
+
+Fp12 f12_pow_words(const Fp12 &a, const uint64_t *e, int nwords) {
+    Fp12 r = Fp12::one();
+    bool started = false;
+    for (int i = nwords - 1; i >= 0; i--)
+        for (int b = 63; b >= 0; b--) {
+            if (started) r = f12_mul(r, r);
+            if ((e[i] >> b) & 1) {
+                r = started ? f12_mul(r, a) : a;
+                started = true;
+            }
+        }
+    return r;
+}
+
+struct G2Aff {
+    HFp2 x, y;
+    bool inf;
+};
+struct G1Aff {
+    HFp x, y;
+    bool inf;
+};
+
+// line through T1, T2 (twist points, affine) evaluated at P; also returns T1 + T2 in *sum.
+Fp12 line_and_add(const G2Aff &t1, const G2Aff &t2, const G1Aff &p, G2Aff *sum) {
+    Fp12 l;
+    for (auto &x : l.c) x = HFp2::zero();
+    HFp2 m;
+    if (!t1.x.equals(t2.x)) {
+        m = fe_mul(fe_sub(t2.y, t1.y), fe_inv(fe_sub(t2.x, t1.x)));
+    } else if (t1.y.equals(t2.y)) {
+        const HFp2 x2 = fe_sqr(t1.x);
+        m = fe_mul(fe_add(fe_dbl(x2), x2), fe_inv(fe_dbl(t1.y)));
+    } else {  // vertical line: x_P - x_1 w^2, sum is infinity
+        l.c[0] = fp2_from_fp(p.x);
+        l.c[2] = fe_neg(t1.x);
+        sum->inf = true;
+        return l;
+    }
+    l.c[0] = fp2_from_fp(fe_neg(p.y));
+    l.c[1] = fp2_mul_fp(m, p.x);
+    l.c[3] = fe_sub(t1.y, fe_mul(m, t1.x));
+    const HFp2 nx = fe_sub(fe_sub(fe_sqr(m), t1.x), t2.x);
+    const HFp2 ny = fe_sub(fe_mul(m, fe_sub(t1.x, nx)), t1.y);
+    sum->x = nx;
+    sum->y = ny;
+    sum->inf = false;
+    return l;
+}
+
+HFp fp_from_words32(const uint32_t *w) { return fe_to_mont(HFp::from_words(w)); }
+
+Fp12 miller_loop(const G2Aff &q, const G1Aff &p) {
+    if (q.inf || p.inf) return Fp12::one();
+    static const uint32_t fx0[8] = ZK_FROB_X_C0, fx1[8] = ZK_FROB_X_C1, fy0[8] = ZK_FROB_Y_C0, fy1[8] = ZK_FROB_Y_C1;
+    static const HFp2 frob_x{fp_from_words32(fx0), fp_from_words32(fx1)}, frob_y{fp_from_words32(fy0), fp_from_words32(fy1)};
+    const uint64_t ate = ZK_ATE_LOOP_LOW64;  // low 64 bits of 6u+2; the 65th bit is the start R = Q
+    G2Aff r = q;
+    Fp12 f = Fp12::one();
+    for (int i = 63; i >= 0; i--) {
+        G2Aff nr;
+        const Fp12 l = line_and_add(r, r, p, &nr);
+        f = f12_mul(f12_mul(f, f), l);
+        r = nr;
+        if ((ate >> i) & 1) {
+            const Fp12 l2 = line_and_add(r, q, p, &nr);
+            f = f12_mul(f, l2);
+            r = nr;
+        }
+    }
+    // Frobenius images of Q on the twist: pi(x, y) = (conj(x) * xi^((p-1)/3), conj(y) * xi^((p-1)/2))
+    G2Aff q1{fe_mul(fp2_conj(q.x), frob_x), fe_mul(fp2_conj(q.y), frob_y), false};
+    G2Aff q2{fe_mul(fp2_conj(q1.x), frob_x), fe_neg(fe_mul(fp2_conj(q1.y), frob_y)), false};
+    G2Aff nr;
+    f = f12_mul(f, line_and_add(r, q1, p, &nr));
+    r = nr;
+    f = f12_mul(f, line_and_add(r, q2, p, &nr));
+    return f;
+}
+
+Fp12 final_exp(const Fp12 &f) {
+    static const uint64_t e[ZK_FINAL_EXP_WORDS] = ZK_FINAL_EXP;
+    return f12_pow_words(f, e, ZK_FINAL_EXP_WORDS);
+}
+
+G1Aff load_g1(const uint64_t *p) {
+    G1Aff a;
+    a.x = read_fe_canonical_fp(p);
+    a.y = read_fe_canonical_fp(p + 4);
+    a.inf = a.x.is_zero() && a.y.is_zero();
+    return a;
+}
+G2Aff load_g2(const uint64_t *p) {
+    G2Aff a;
+    a.x = HFp2{read_fe_canonical_fp(p), read_fe_canonical_fp(p + 4)};
+    a.y = HFp2{read_fe_canonical_fp(p + 8), read_fe_canonical_fp(p + 12)};
+    a.inf = a.x.is_zero() && a.y.is_zero();
+    return a;
+}
+
+}  // namespace
+
+// prod_i e(P_i, Q_i) with ONE final exponentiation; out (nullable): 12 canonical F_p coefficients
+// in py_ecc's F_p[w]/(w^12 - 18 w^6 + 82) basis; *is_one: whether the product is the identity.
+int pairing_product(const uint64_t *g1_points, const uint64_t *g2_points, size_t n, uint64_t *out, int *is_one) {
+    Fp12 f = Fp12::one();
+    for (size_t i = 0; i < n; i++) f = f12_mul(f, miller_loop(load_g2(g2_points + 16 * i), load_g1(g1_points + 8 * i)));
+    f = final_exp(f);
+    if (is_one) *is_one = f.equals(Fp12::one()) ? 1 : 0;
+    if (out) {
+        // c[k] = a + b i with i = w^6 - 9  ->  coefficient of w^k: a - 9 b, of w^(k+6): b
+        for (int k = 0; k < 6; k++) {
+            HFp nine_b = fe_add(fe_dbl(fe_dbl(fe_dbl(f.c[k].c1))), f.c[k].c1);
+            HFp lo = fe_from_mont(fe_sub(f.c[k].c0, nine_b)), hi = fe_from_mont(f.c[k].c1);
+            memcpy(out + 4 * k, lo.l, 32);
+            memcpy(out + 4 * (k + 6), hi.l, 32);
+        }
+    }
+    return ZK_OK;
+}
+
+}  // namespace zk

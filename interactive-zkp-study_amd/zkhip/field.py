@@ -286,7 +286,85 @@ def ec_neg(point):
     return (point[0], -point[1])
 
 
-mult, add, neg = ec_mul, ec_add, ec_neg  # zkp/groth16/proving.py:12-15 aliases
+class FQ12:
+    """Target-group element: 12 coefficients of F_p[w]/(w^12 - 18 w^6 + 82) (py_ecc bn128_FQ12 order).
+    Supports what the verifiers use: ==, * and ** (zkp/groth16/verifying.py:29-40)."""
+    __slots__ = ("coeffs",)
+
+    def __init__(self, coeffs):
+        self.coeffs = tuple(FQ(c) for c in coeffs)
+        if len(self.coeffs) != 12:
+            raise ValueError("FQ12 needs 12 coefficients")
+
+    @classmethod
+    def one(cls):
+        return cls([1] + [0] * 11)
+
+    def __mul__(self, other):
+        if isinstance(other, (int, FQ)):
+            return FQ12([c * other for c in self.coeffs])
+        a, b = [c.n for c in self.coeffs], [c.n for c in other.coeffs]
+        t = [0] * 23
+        for i, x in enumerate(a):
+            if x:
+                for j, y in enumerate(b):
+                    t[i + j] += x * y
+        for k in range(22, 11, -1):  # w^12 = 18 w^6 - 82
+            if t[k]:
+                t[k - 6] += 18 * t[k]
+                t[k - 12] -= 82 * t[k]
+        return FQ12(t[:12])
+
+    __rmul__ = __mul__
+
+    def __pow__(self, e):
+        e = int(e)
+        r, base = FQ12.one(), self
+        while e:
+            if e & 1:
+                r = r * base
+            base = base * base
+            e >>= 1
+        return r
+
+    def __eq__(self, other):
+        if isinstance(other, FQ12):
+            return self.coeffs == other.coeffs
+        return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    def __hash__(self):
+        return hash(self.coeffs)
+
+    def __repr__(self):
+        return "FQ12(%r)" % ([c.n for c in self.coeffs],)
+
+
+def ec_pairing(g2_point, g1_point):
+    """e(g1_point, g2_point) -> FQ12; argument order (G2, G1) as py_ecc.bn128.pairing and
+    zkp/plonk/field.py:118-138.  Runs on the host (zk_pairing): a verifier needs 2-4 pairings."""
+    P = g1_to_limbs([g1_point])
+    Q = g2_to_limbs([g2_point])
+    out = np.zeros(48, dtype=np.uint64)
+    _lib.check(_lib.load().zk_pairing(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(out)))
+    return FQ12(_lib.limbs_to_ints(out))
+
+
+def pairing_check(pairs):
+    """True iff prod_i e(P_i, Q_i) == 1 for pairs [(P_i in G1, Q_i in G2), ...] (one final exponentiation)."""
+    if not pairs:
+        return True
+    P = g1_to_limbs([p for p, _ in pairs])
+    Q = g2_to_limbs([q for _, q in pairs])
+    ok = _lib.ctypes.c_int(0)
+    _lib.check(_lib.load().zk_pairing_check(_lib.ptr(P), _lib.ptr(Q), len(pairs), _lib.ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+mult, add, neg, pairing = ec_mul, ec_add, ec_neg, ec_pairing  # zkp/groth16/proving.py:12-15 aliases
 
 
 def get_root_of_unity(n):

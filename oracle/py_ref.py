@@ -537,3 +537,177 @@ def toy_groth16():
                 Ax_val=Axv, Bx_val=Bxv, Cx_val=Cxv, Zx_val=Zxv,
                 s11=s11, s12=s12, s13=s13, s14=s14, s15=s15, s21=s21, s22=s22,
                 proof_A=pa, proof_B=pb, proof_C=pc, A=A, B=B, C=C)
+
+
+# ----------------------------------------------------------------------------- pairing (py_ecc shape)
+# Restatement of py_ecc/bn128/bn128_pairing.py + bn128_curve.py (twist) + fields (FQ12 as
+# F_p[w]/(w^12 - 18 w^6 + 82)), used by the reference through `pairing(Q, P)`:
+# zkp/groth16/verifying.py:17-40, zkp/plonk/field.py:118-138, zkp/plonk/kzg.py:117-160.
+FQ12_MOD = [82, 0, 0, 0, 0, 0, -18, 0, 0, 0, 0, 0]  # w^12 = 18 w^6 - 82
+ATE_LOOP_COUNT = 29793968203157093288
+LOG_ATE_LOOP_COUNT = 63
+
+
+def f12(coeffs):
+    return [c % P for c in coeffs]
+
+
+F12_ONE = f12([1] + [0] * 11)
+F12_ZERO = [0] * 12
+
+
+def f12_add(a, b):
+    return [(x + y) % P for x, y in zip(a, b)]
+
+
+def f12_sub(a, b):
+    return [(x - y) % P for x, y in zip(a, b)]
+
+
+def f12_mul(a, b):
+    t = [0] * 23
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                t[i + j] += x * y
+    for k in range(22, 11, -1):  # w^k = 18 w^(k-6) - 82 w^(k-12)
+        top = t[k]
+        if top:
+            t[k - 6] += 18 * top
+            t[k - 12] -= 82 * top
+    return [v % P for v in t[:12]]
+
+
+def f12_smul(a, k):
+    return [x * k % P for x in a]
+
+
+def _poly_deg(p):
+    d = len(p) - 1
+    while d and p[d] == 0:
+        d -= 1
+    return d
+
+
+def f12_inv(a):
+    """Extended Euclid in F_p[w] (py_ecc FQP.inv)."""
+    lm, hm = [1] + [0] * 12, [0] * 13
+    low, high = list(a) + [0], [v % P for v in FQ12_MOD] + [1]
+    while _poly_deg(low):
+        # r = high / low (polynomial division, quotient only)
+        dega, degb = _poly_deg(high), _poly_deg(low)
+        temp, o = list(high), [0] * 13
+        inv_lead = pow(low[degb], -1, P)
+        for i in range(dega - degb, -1, -1):
+            q = temp[degb + i] * inv_lead % P
+            o[i] = q
+            for c in range(degb + 1):
+                temp[c + i] = (temp[c + i] - low[c] * q) % P
+        r = o
+        nm, new = list(hm), list(high)
+        for i in range(13):
+            for j in range(13 - i):
+                nm[i + j] = (nm[i + j] - lm[i] * r[j]) % P
+                new[i + j] = (new[i + j] - low[i] * r[j]) % P
+        lm, low, hm, high = nm, new, lm, low
+    inv0 = pow(low[0], -1, P)
+    return [v * inv0 % P for v in lm[:12]]
+
+
+def f12_pow(a, e):
+    r, base = list(F12_ONE), list(a)
+    while e:
+        if e & 1:
+            r = f12_mul(r, base)
+        base = f12_mul(base, base)
+        e >>= 1
+    return r
+
+
+def twist(pt):
+    """E'(F_p^2) -> E(F_p^12)  (py_ecc bn128_curve.twist)."""
+    if pt is None:
+        return None
+    (x0, x1), (y0, y1) = pt
+    nx = f12([x0 - 9 * x1] + [0] * 5 + [x1] + [0] * 5)
+    ny = f12([y0 - 9 * y1] + [0] * 5 + [y1] + [0] * 5)
+    w2 = f12([0, 0, 1] + [0] * 9)
+    w3 = f12([0, 0, 0, 1] + [0] * 8)
+    return (f12_mul(nx, w2), f12_mul(ny, w3))
+
+
+def cast_g1_to_f12(pt):
+    if pt is None:
+        return None
+    return (f12([pt[0]] + [0] * 11), f12([pt[1]] + [0] * 11))
+
+
+def _f12_pt_double(pt):
+    x, y = pt
+    m = f12_mul(f12_smul(f12_mul(x, x), 3), f12_inv(f12_smul(y, 2)))
+    nx = f12_sub(f12_mul(m, m), f12_smul(x, 2))
+    ny = f12_sub(f12_sub(f12_mul(m, x), f12_mul(m, nx)), y)
+    return (nx, ny)
+
+
+def _f12_pt_add(p1, p2):
+    if p1 is None or p2 is None:
+        return p1 if p2 is None else p2
+    x1, y1 = p1
+    x2, y2 = p2
+    if x2 == x1 and y2 == y1:
+        return _f12_pt_double(p1)
+    if x2 == x1:
+        return None
+    m = f12_mul(f12_sub(y2, y1), f12_inv(f12_sub(x2, x1)))
+    nx = f12_sub(f12_sub(f12_mul(m, m), x1), x2)
+    ny = f12_sub(f12_sub(f12_mul(m, x1), f12_mul(m, nx)), y1)
+    return (nx, ny)
+
+
+def linefunc(P1, P2, T):
+    """py_ecc bn128_pairing.linefunc on F_p^12 points."""
+    x1, y1 = P1
+    x2, y2 = P2
+    xt, yt = T
+    if x1 != x2:
+        m = f12_mul(f12_sub(y2, y1), f12_inv(f12_sub(x2, x1)))
+        return f12_sub(f12_mul(m, f12_sub(xt, x1)), f12_sub(yt, y1))
+    if y1 == y2:
+        m = f12_mul(f12_smul(f12_mul(x1, x1), 3), f12_inv(f12_smul(y1, 2)))
+        return f12_sub(f12_mul(m, f12_sub(xt, x1)), f12_sub(yt, y1))
+    return f12_sub(xt, x1)
+
+
+def miller_loop(Q, Pt):
+    if Q is None or Pt is None:
+        return list(F12_ONE)
+    R, f = Q, list(F12_ONE)
+    for i in range(LOG_ATE_LOOP_COUNT, -1, -1):
+        f = f12_mul(f12_mul(f, f), linefunc(R, R, Pt))
+        R = _f12_pt_double(R)
+        if ATE_LOOP_COUNT & (1 << i):
+            f = f12_mul(f, linefunc(R, Q, Pt))
+            R = _f12_pt_add(R, Q)
+    Q1 = (f12_pow(Q[0], P), f12_pow(Q[1], P))
+    nQ2 = (f12_pow(Q1[0], P), [(-v) % P for v in f12_pow(Q1[1], P)])
+    f = f12_mul(f, linefunc(R, Q1, Pt))
+    R = _f12_pt_add(R, Q1)
+    f = f12_mul(f, linefunc(R, nQ2, Pt))
+    return f12_pow(f, (P ** 12 - 1) // CURVE_ORDER)
+
+
+def pairing(Q, Pt):
+    """py_ecc.bn128.pairing(Q in G2, P in G1) -> F_p^12 coefficient list (12 ints)."""
+    return miller_loop(twist(Q), cast_g1_to_f12(Pt))
+
+
+def groth16_verify(prf_A, prf_B, prf_C, sigma1_1, sigma1_3, sigma2_1, rx_pub):
+    """zkp/groth16/verifying.py:29-40."""
+    lhs = pairing(prf_B, prf_A)
+    rhs = pairing(sigma2_1[0], sigma1_1[0])
+    temp = None
+    for i, ri in rx_pub:
+        temp = g1_add(temp, g1_multiply(sigma1_3[i], int(ri) % R))
+    rhs = f12_mul(f12_mul(rhs, pairing(sigma2_1[1], temp)), pairing(sigma2_1[2], prf_C))
+    return lhs == rhs

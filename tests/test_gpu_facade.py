@@ -9,13 +9,14 @@ import os
 import pytest
 
 import py_ref as o
-from zkhip.field import (FQ, FQ2, FR, G1, G2, Z1, CURVE_ORDER, ec_add, ec_mul, ec_neg, get_root_of_unity,
+from zkhip.field import (FQ, FQ2, FQ12, FR, G1, G2, Z1, CURVE_ORDER, ec_add, ec_mul, ec_neg, ec_pairing, get_root_of_unity,
                          get_roots_of_unity)
 from zkhip.groth16.poly_utils import (ax_val, bx_val, cx_val, getFRPoly1D, getFRPoly2D, getNumGates, getNumWires,
                                       hx_val, hxr, zx_val)
 from zkhip.groth16.proving import build_rpub_enum, proof_a, proof_b, proof_c
 from zkhip.groth16.setup import sigma11, sigma12, sigma13, sigma14, sigma15, sigma21, sigma22
-from zkhip.plonk.kzg import commit
+from zkhip.groth16.verifying import lhs, rhs, verify
+from zkhip.plonk.kzg import commit, create_witness, verify_opening
 from zkhip.plonk.polynomial import Polynomial, fft, ifft, poly_div
 from zkhip.plonk.srs import SRS
 from zkhip.plonk.utils import coset_fft, coset_ifft
@@ -247,3 +248,38 @@ def test_commit_linearity(srs_small):
     assert commit(p + Polynomial([FR(0)]), srs_small) == commit(p, srs_small)
     poly, s = Polynomial([FR(2), FR(3)]), FR(5)
     assert commit(poly * s, srs_small) == ec_mul(commit(poly, srs_small), s)
+
+
+# ------------------------------------------------------------------ verify (tests/groth16/test_verifying.py, test_integration.py:59-79)
+def test_groth16_verify_true_and_tampered(pipeline):
+    p = pipeline
+    rx_pub = build_rpub_enum(p["t"]["pub"], p["Rx"])
+    assert verify(p["prf_A"], p["prf_B"], p["prf_C"], p["s11"], p["s13"], p["s21"], rx_pub) is True
+    assert lhs(p["prf_A"], p["prf_B"]) == rhs(p["prf_C"], p["s11"], p["s13"], p["s21"], rx_pub)
+    assert verify(ec_add(p["prf_A"], G1), p["prf_B"], p["prf_C"], p["s11"], p["s13"], p["s21"], rx_pub) is False
+    assert verify(p["prf_A"], ec_add(p["prf_B"], G2), p["prf_C"], p["s11"], p["s13"], p["s21"], rx_pub) is False
+    assert verify(p["prf_A"], p["prf_B"], ec_mul(p["prf_C"], 2), p["s11"], p["s13"], p["s21"], rx_pub) is False
+    wrong_pub = [(0, FR(1)), (1, FR(4))]                                       # wrong public input
+    assert verify(p["prf_A"], p["prf_B"], p["prf_C"], p["s11"], p["s13"], p["s21"], wrong_pub) is False
+
+
+def test_pairing_wrapper_bilinear():
+    e = ec_pairing(G2, G1)
+    assert isinstance(e, FQ12) and e != FQ12.one()
+    assert ec_pairing(G2, ec_mul(G1, 5)) == e ** 5 == ec_pairing(ec_mul(G2, 5), G1)
+    assert ec_pairing(ec_mul(G2, 3), ec_mul(G1, 4)) == e ** 12
+    assert e ** CURVE_ORDER == FQ12.one()
+
+
+# ------------------------------------------------------------------ KZG openings (tests/plonk/test_crypto.py:198-301)
+def test_kzg_openings(srs_small):
+    p = Polynomial([FR(1), FR(2), FR(3), FR(4)])
+    C = commit(p, srs_small)
+    for z in (FR(0), FR(3), FR(7), FR(123456789)):
+        pi = create_witness(p, z, srs_small)
+        y = p.evaluate(z)
+        assert verify_opening(C, pi, z, y, srs_small) is True
+        assert verify_opening(C, pi, z, y + FR(1), srs_small) is False          # wrong evaluation
+        assert verify_opening(C, pi, z + FR(1), y, srs_small) is False          # wrong point
+    const = Polynomial([FR(9)])
+    assert verify_opening(commit(const, srs_small), create_witness(const, FR(5), srs_small), FR(5), FR(9), srs_small)
