@@ -43,6 +43,42 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// R butterfly stages (s_hi .. s_hi-R+1) on 2^R elements held in registers: LDS is read and written
+// once per element per round instead of once per stage, and a stage's twiddle is fetched once per
+// 2^(R-1-b) butterflies.  Values stay < 2r (see the pass kernel).
+template <int R>
+__device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, uint32_t tile, uint32_t ntw, uint32_t lp, uint32_t g,
+                                          int s_hi) {
+    const int s_lo = s_hi - R + 1;
+    const uint32_t ngroups = tile >> R;
+    for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NTT_NT) {
+        const uint32_t c = gi & ((1u << g) - 1u), rest = gi >> g;
+        const uint32_t low = rest & ((1u << s_lo) - 1u);
+        const uint32_t jb = ((rest >> s_lo) << (s_hi + 1)) | low;
+        Fr x[1 << R];
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) x[k] = lds_ld(data, tile, ((jb | ((uint32_t)k << s_lo)) << g) | c);
+#pragma unroll
+        for (int b = R - 1; b >= 0; b--) {
+            const int s = s_lo + b;
+#pragma unroll
+            for (int q = 0; q < (1 << b); q++) {
+                const Fr w = lds_ld(tw, ntw, (low | ((uint32_t)q << s_lo)) << (lp - 1 - s));
+#pragma unroll
+                for (int hi = 0; hi < (1 << (R - 1 - b)); hi++) {
+                    const int k0 = (hi << (b + 1)) | q, k1 = k0 | (1 << b);
+                    Fr sum = fe_add(x[k0], x[k1]);  // < 4r
+                    fe_wreduce<4>(sum);             // < 2r
+                    x[k1] = fe_mul(fe_sub_k<2>(x[k0], x[k1]), w);  // (a - b + 2r) < 4r, w < r  ->  < 2r
+                    x[k0] = sum;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) lds_st(data, tile, ((jb | ((uint32_t)k << s_lo)) << g) | c, x[k]);
+    }
+}
+
 // One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
 // passes (lazy 9-limb form, 36 B); only the first load and the last store use the canonical
 // 32-byte encoding.  LDS: data[9][tile] (limb-major) | tw[9][2^(lp-1)].
@@ -87,21 +123,18 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     }
     __syncthreads();
 
-    // decimation-in-frequency butterflies over the digit index j (slot = j * G + c)
-    for (int s = (int)lp - 1; s >= 0; s--) {
-        const uint32_t half = 1u << s;
-        for (uint32_t b = t; b < (tile >> 1); b += NTT_NT) {
-            const uint32_t c = b & (G - 1u), jj = b >> g;
-            const uint32_t jl = jj & (half - 1u);
-            const uint32_t j = ((jj >> s) << (s + 1)) | jl;
-            const uint32_t sa = (j << g) | c, sb = sa + (half << g);
-            const Fr a = lds_ld(data, tile, sa), bb = lds_ld(data, tile, sb);
-            const Fr w = lds_ld(tw, ntw, jl << (lp - 1 - s));
-            Fr sum = fe_add(a, bb);                       // < 4r
-            fe_wreduce<4>(sum);                           // < 2r
-            lds_st(data, tile, sa, sum);
-            lds_st(data, tile, sb, fe_mul(fe_sub_k<2>(a, bb), w));  // (a - b + 2r) < 4r, w < r  ->  < 2r
-        }
+    // decimation-in-frequency butterflies over the digit index j (slot = j * G + c), up to three
+    // stages per LDS round trip (radix-8 / radix-4 in registers)
+    for (int sh = (int)lp - 1; sh >= 0;) {
+        const int rem = sh + 1;
+        const int R = (rem >= 5 || rem == 3) ? 3 : (rem == 1 ? 1 : 2);
+        if (R == 3)
+            ntt_round<3>(data, tw, tile, ntw, lp, g, sh);
+        else if (R == 2)
+            ntt_round<2>(data, tw, tile, ntw, lp, g, sh);
+        else
+            ntt_round<1>(data, tw, tile, ntw, lp, g, sh);
+        sh -= R;
         __syncthreads();
     }
 
@@ -250,7 +283,8 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
             P.L = L_; P.lp = lp; P.sp = sp; P.lh = lh_;
             P.tw_shift = lmax_ - lp;
             const bool final_pass = (p == D - 1);
-            P.g = (D == 1) ? 0 : NTT_G;
+            // tiles of up to 2^11 elements (every thread owns 8), but never fewer than ~512 tiles per pass
+            P.g = (D == 1) ? 0 : (uint32_t)std::max<int>(NTT_G, std::min<int>(11 - (int)lp, (int)L_ - (int)lp - 9));
             const void *src = (p == 0) ? static_cast<const void *>(data) : tmp_.p;
             void *dst = final_pass ? static_cast<void *>(data) : tmp_.p;
             const uint32_t tile = 1u << (lp + P.g);
