@@ -3,12 +3,17 @@
 // Replaces fft / ifft (zkp/plonk/polynomial.py:292-378) and coset_fft / coset_ifft
 // (zkp/plonk/utils.py:145-205).  n = 2^L is factored into D = ceil(L/8) digits n_1..n_D
 // (multi-step / Stockham-style autosort): pass p transforms digit p of every element inside an
-// LDS tile of 2^(l_p) x 8 elements (8 adjacent elements per digit value keep every HBM access a
-// 256-byte run), multiplies by the inter-pass twiddle w_n^(k_p * rem) and writes back; the last
-// pass transforms the contiguous digit and writes to the digit-reversed position, which makes
-// the output natural-order with no separate bit-reversal pass.  Data stays in canonical form:
-// only the twiddles are in Montgomery form (mont_mul(x, w*R) = x*w), so no conversion pass.
-// Each element is read and written once per pass: D * 64 bytes of HBM traffic per element.
+// LDS tile of 2^(l_p) x 2^g elements (2^g >= 8 adjacent elements per digit value keep every HBM
+// access a >= 256-byte run), multiplies by the inter-pass twiddle w_n^(k_p * rem) (two-level
+// table) and writes back; the last pass transforms the contiguous digit and writes to the
+// digit-reversed position, which makes the output natural-order with no separate bit-reversal
+// pass.  Inside a tile the decimation-in-frequency butterflies run three stages at a time on 8
+// elements held in registers (one LDS round trip per three stages).  Element VALUES are never
+// converted to Montgomery form: only the twiddles are (mont_mul(x, w*R) = x*w); elements are
+// kept as lazy 9x29-bit limbs (< 2r) in LDS and in the scratch buffer between passes, and are
+// canonical 32-byte words only at the first load and the last store.
+// HBM traffic: 64..72 bytes per element per pass; the kernel is bound by the ~15 modular
+// products per element (butterflies + 2 per pass boundary), not by bandwidth.
 #include <string.h>
 #include "common.h"
 #include "ntt.h"
