@@ -79,6 +79,13 @@ int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, s
  * G1 = 4*4 limbs X,Y,ZZ,ZZZ Montgomery form; G2 = 4*8 limbs) for multi-GPU folding. */
 int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n,
                        uint64_t *out_xyzz, void *stream);
+/* Pipelined form of the two calls above: zk_msm_submit enqueues the whole GPU pipeline (and the
+ * 36 KiB read-back) on `stream` and returns at once with a ticket; zk_msm_collect / _collect_partial
+ * wait for that submission and do the host fold.  Up to TWO submissions may be in flight per plan, so
+ * the host fold of MSM k overlaps the GPU work of MSM k+1 (a prover issues 5-17 MSMs back to back). */
+int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket);
+int zk_msm_collect(zk_msm_plan *plan, int ticket, uint64_t *out_xy, int *out_is_inf);
+int zk_msm_collect_partial(zk_msm_plan *plan, int ticket, uint64_t *out_xyzz);
 /* Folds `count` partial sums (as written by zk_msm_dev_partial, e.g. all-gathered over RCCL
  * from the ranks that each hold a chunk of the points) in rank order into one affine point.
  * Host-side, O(count) group additions; this is the "all-reduce of partial sums" epilogue

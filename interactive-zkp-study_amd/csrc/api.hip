@@ -204,6 +204,25 @@ int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_p
         return plan->impl->run_partial(d_scalars, d_points, n, out_xyzz, (hipStream_t)stream);
     });
 }
+int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket) {
+    return guarded([&] {
+        if (!plan || !out_ticket || (n && (!d_scalars || !d_points))) return invalid("zk_msm_submit: null pointer");
+        *out_ticket = plan->impl->submit(d_scalars, d_points, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_msm_collect(zk_msm_plan *plan, int ticket, uint64_t *out_xy, int *out_is_inf) {
+    return guarded([&] {
+        if (!plan || !out_xy) return invalid("zk_msm_collect: null pointer");
+        return plan->impl->collect_affine(ticket, out_xy, out_is_inf);
+    });
+}
+int zk_msm_collect_partial(zk_msm_plan *plan, int ticket, uint64_t *out_xyzz) {
+    return guarded([&] {
+        if (!plan || !out_xyzz) return invalid("zk_msm_collect_partial: null pointer");
+        return plan->impl->collect_partial(ticket, out_xyzz);
+    });
+}
 int zk_msm_partial_limbs(int group) { return group == ZK_GROUP_G1 ? 16 : group == ZK_GROUP_G2 ? 32 : ZK_ERR_INVALID; }
 int zk_msm_fold_partials(int group, const uint64_t *partials, size_t count, uint64_t *out_xy, int *out_is_inf) {
     return guarded([&] {

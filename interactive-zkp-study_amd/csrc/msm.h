@@ -15,6 +15,10 @@ struct MsmPlanBase {
     virtual int window_bits(size_t n) const = 0;
     virtual int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) = 0;
     virtual int run_partial(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, hipStream_t st) = 0;
+    // pipelined form: up to two submissions in flight per plan
+    virtual int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) = 0;
+    virtual int collect_affine(int ticket, uint64_t *out_xy, int *out_is_inf) = 0;
+    virtual int collect_partial(int ticket, uint64_t *out_xyzz) = 0;
 };
 MsmPlanBase *msm_plan_new_g1(size_t max_n);
 MsmPlanBase *msm_plan_new_g2(size_t max_n);

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64) void msm_heavy_combine_kernel(SortBufs B, const
 //   thread per step, depth = number of levels.
 // Afterwards O_l = x[2^l] and T = x[0] (per block for the block kernel, per window at the end).
 template <class F>
-__global__ __launch_bounds__(256) void msm_reduce_block_kernel(Xyzz<F> *x, uint32_t BL) {
+__global__ __launch_bounds__(256, (F::CANON_WORDS == 8 ? 4 : 1)) void msm_reduce_block_kernel(Xyzz<F> *x, uint32_t BL) {
     Xyzz<F> *blk = x + ((size_t)blockIdx.x << BL);
     const uint32_t t = threadIdx.x;
     for (uint32_t s = 0; s < BL; s++) {
@@ -590,8 +590,17 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     size_t max_n;
     DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
     uint32_t heavy_cap = 0;
-    PinnedBuf h_out;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
+    // Two submissions may be in flight: the 36 KiB read-back buffer, its completion event and the
+    // profiling events are per slot, everything else is reused in stream order.
+    static constexpr int SLOTS = 2;
+    struct Slot {
+        PinnedBuf h_out;
+        hipEvent_t done = nullptr;
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
+        bool busy = false, empty = false, profiled = false;
+        int c = 0;
+    } slots[SLOTS];
+    int next_slot = 0, cur = 0;
 
     static constexpr int MAXC = 16;
     explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
@@ -626,17 +635,21 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         perm.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         arena.alloc(ar);
         out.alloc(outn);
-        h_out.alloc(outn);
+        for (auto &sl : slots) sl.h_out.alloc(outn);
     }
     ~MsmPlanImpl() override {
-        for (auto &e : ev)
-            if (e) (void)hipEventDestroy(e);
+        for (auto &sl : slots) {
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            for (auto &e : sl.ev)
+                if (e) (void)hipEventDestroy(e);
+        }
     }
     static size_t pad_n(size_t n) { return ((n + 4095) / 4096) * 4096; }
     void mark(int i, hipStream_t st) {
         if (!profile) return;
-        if (!ev[i]) ZK_HIP(hipEventCreate(&ev[i]));
-        ZK_HIP(hipEventRecord(ev[i], st));
+        hipEvent_t &e = slots[cur].ev[i];
+        if (!e) ZK_HIP(hipEventCreate(&e));
+        ZK_HIP(hipEventRecord(e, st));
     }
 
     int window_bits(size_t n) const override { return pick_window_bits(n); }
@@ -685,11 +698,19 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(std::min<uint32_t>(max_tasks, 1024)), dim3(64), 0, st, B, heavy_partial.as<Xyzz<F>>(), arena.as<Xyzz<F>>());
     }
 
-    // Enqueues the GPU pipeline and reads the window/level sums back; returns the XYZZ result.
-    Xyzz<HF> run(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
-        if (n == 0) return Xyzz<HF>::inf();
+    // Enqueues the whole GPU pipeline plus the 36 KiB read-back on `st`; returns a ticket.
+    int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) override {
         if (n > max_n) throw std::runtime_error("zk_msm: n exceeds the plan's max_n");
+        cur = next_slot;
+        Slot &sl = slots[cur];
+        if (sl.busy) throw std::runtime_error("zk_msm: more than two submissions in flight; collect the oldest first");
+        sl.busy = true;
+        sl.empty = (n == 0);
+        sl.profiled = profile;
+        next_slot = (next_slot + 1) % SLOTS;
+        if (n == 0) return cur;
         const int c = pick_window_bits(n);
+        sl.c = c;
         const uint32_t W = (255 + c - 1) / c, nb = 1u << (c - 1), levels = c - 1;
         const uint32_t n_pad = (uint32_t)pad_n(n);
         const uint32_t *sc = static_cast<const uint32_t *>(d_scalars), *pt = static_cast<const uint32_t *>(d_points);
@@ -704,7 +725,6 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(1, st);
         launch_sort_accumulate(n_pad, nb, W, st);
         mark(3, st);
-
         {
             Xyzz<F> *ar = arena.as<Xyzz<F>>();
             const uint32_t BL = std::min<uint32_t>(9, levels);
@@ -714,15 +734,27 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         }
         mark(4, st);
         const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
-        ZK_HIP(hipMemcpyAsync(h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
-        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipMemcpyAsync(sl.h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
+        if (!sl.done) ZK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        ZK_HIP(hipEventRecord(sl.done, st));
         ZK_HIP(hipGetLastError());
-        if (profile) {
-            for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]));
-        }
+        return cur;
+    }
 
+    // Waits for a submission and folds its window/level sums on the host.
+    Xyzz<HF> collect(int ticket) {
+        if (ticket < 0 || ticket >= SLOTS || !slots[ticket].busy) throw std::runtime_error("zk_msm: bad ticket");
+        Slot &sl = slots[ticket];
+        sl.busy = false;
+        if (sl.empty) return Xyzz<HF>::inf();
+        ZK_HIP(hipEventSynchronize(sl.done));
+        if (sl.profiled) {
+            for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], sl.ev[i], sl.ev[i + 1]));
+        }
+        const int c = sl.c;
+        const uint32_t W = (255 + c - 1) / c, levels = c - 1;
         // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
-        const Xyzz<F> *h = h_out.as<Xyzz<F>>();
+        const Xyzz<F> *h = sl.h_out.template as<Xyzz<F>>();
         auto conv = [](const Xyzz<F> &p) { return Xyzz<HF>{HF::from_dev(p.x), HF::from_dev(p.y), HF::from_dev(p.zz), HF::from_dev(p.zzz)}; };
         Xyzz<HF> acc = Xyzz<HF>::inf();
         for (int pos = (int)(c * (W - 1) + levels - 1); pos >= 0; pos--) {
@@ -733,6 +765,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         }
         return acc;
     }
+    int collect_affine(int ticket, uint64_t *out_xy, int *out_is_inf) override {
+        write_affine<F>(collect(ticket), out_xy, out_is_inf);
+        return ZK_OK;
+    }
+    int collect_partial(int ticket, uint64_t *out_xyzz) override {
+        Xyzz<HF> r = collect(ticket);
+        memcpy(out_xyzz, &r, sizeof(r));
+        return ZK_OK;
+    }
+    Xyzz<HF> run(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) { return collect(submit(d_scalars, d_points, n, st)); }
 
     int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) override {
         Xyzz<HF> r = run(d_scalars, d_points, n, st);

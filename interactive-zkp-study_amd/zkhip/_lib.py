@@ -45,6 +45,9 @@ _PROTOS = {
     "zk_msm_plan_stage_ms": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
     "zk_msm_dev": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int), _VP]),
     "zk_msm_dev_partial": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP]),
+    "zk_msm_submit": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
+    "zk_msm_collect": (ctypes.c_int, [_VP, ctypes.c_int, _VP, ctypes.POINTER(ctypes.c_int)]),
+    "zk_msm_collect_partial": (ctypes.c_int, [_VP, ctypes.c_int, _VP]),
     "zk_msm_fold_partials": (ctypes.c_int, [ctypes.c_int, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
     "zk_msm_partial_limbs": (ctypes.c_int, [ctypes.c_int]),
     "zk_ntt_fr": (ctypes.c_int, [_VP, ctypes.c_uint, ctypes.c_int, _VP]),

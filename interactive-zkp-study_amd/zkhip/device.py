@@ -59,6 +59,23 @@ class MsmPlan:
             return None
         return (limbs_to_g1(out) if self.group == _lib.GROUP_G1 else limbs_to_g2(out))[0]
 
+    # pipelined form: up to two submissions in flight, so the host fold of one MSM overlaps the GPU work of the next
+    def submit(self, d_scalars, d_points, n, stream=0):
+        t = ctypes.c_int(-1)
+        _lib.check(_lib.load().zk_msm_submit(self._h, d_scalars, d_points, n, stream, ctypes.byref(t)))
+        return t.value
+
+    def collect_limbs(self, ticket):
+        out = np.zeros(self._limbs, dtype=np.uint64)
+        inf = ctypes.c_int(0)
+        _lib.check(_lib.load().zk_msm_collect(self._h, ticket, _lib.ptr(out), ctypes.byref(inf)))
+        return out, bool(inf.value)
+
+    def collect_partial(self, ticket):
+        out = np.zeros(2 * self._limbs, dtype=np.uint64)
+        _lib.check(_lib.load().zk_msm_collect_partial(self._h, ticket, _lib.ptr(out)))
+        return out
+
     def run_partial(self, d_scalars, d_points, n, stream=0):
         """-> uint64[16|32]: this device's partial sum in XYZZ Montgomery limbs (for folding)."""
         out = np.zeros(2 * self._limbs, dtype=np.uint64)

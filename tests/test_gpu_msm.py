@@ -147,6 +147,32 @@ def test_device_plan_reuse_partials_and_profile():
     assert co.g1_to_arr([(int(got[0]), int(got[1]))])[0].tolist() == full.tolist()
 
 
+def test_pipelined_submit_collect():
+    """zk_msm_submit / zk_msm_collect: two submissions in flight, results independent of the overlap."""
+    import torch
+    rng = np.random.default_rng(21)
+    n = 30000
+    S1, S2 = rand_fr_limbs(rng, n), rand_fr_limbs(rng, n)
+    Pts, _ = rand_g1_limbs(rng, n)
+    d1, d2 = torch.from_numpy(S1.view(np.int64)).cuda(), torch.from_numpy(S2.view(np.int64)).cuda()
+    dP = torch.from_numpy(Pts.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    t1 = plan.submit(d1.data_ptr(), dP.data_ptr(), n, st)
+    t2 = plan.submit(d2.data_ptr(), dP.data_ptr(), 5000, st)
+    with pytest.raises(_lib.ZkhipError):
+        plan.submit(d1.data_ptr(), dP.data_ptr(), n, st)          # a third one must wait for a collect
+    r1, inf1 = plan.collect_limbs(t1)
+    t3 = plan.submit(d1.data_ptr(), dP.data_ptr(), 0, st)          # empty MSM through the same path
+    r2, inf2 = plan.collect_limbs(t2)
+    r3, inf3 = plan.collect_limbs(t3)
+    assert np.array_equal(r1, co.g1_msm_arr(S1, Pts)) and not inf1
+    assert np.array_equal(r2, co.g1_msm_arr(S2[:5000], Pts[:5000])) and not inf2
+    assert inf3 and not r3.any()
+    with pytest.raises(_lib.ZkhipError):
+        plan.collect_limbs(t1)                                     # already collected
+
+
 def test_g1_msm_2pow16_bit_exact():
     rng = np.random.default_rng(13)
     n = 1 << 16
