@@ -87,19 +87,39 @@ template <class F> static int group_op_host(int op, const uint64_t *p, const uin
     return ZK_OK;
 }
 
+// Host-buffer MSM.  Small calls (the facade's toy-size proofs, verifier combinations) reuse one cached
+// plan per group and thread instead of allocating a workspace per call.
 template <class F> static int msm_host(int group, const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t *out_xy, int *out_is_inf) {
     constexpr size_t PB = 8 * F::CANON_WORDS;
+    constexpr size_t SMALL = 4096;
     if (n == 0) {
         memset(out_xy, 0, PB);
         if (out_is_inf) *out_is_inf = 1;
         return ZK_OK;
     }
     if (!scalars_canonical(scalars, n)) return invalid("zk_msm: scalar not canonical (>= r)");
-    std::unique_ptr<MsmPlanBase> plan(msm_plan_new(group, n));
-    DevBuf ds(n * 32), dp(n * PB);
-    ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
-    ZK_HIP(hipMemcpy(dp.p, points, n * PB, hipMemcpyHostToDevice));
-    return plan->run_affine(ds.p, dp.p, n, out_xy, out_is_inf, 0);
+    static thread_local std::unique_ptr<MsmPlanBase> small_plan[3];
+    static thread_local std::unique_ptr<DevBuf> small_in[3];
+    std::unique_ptr<MsmPlanBase> big_plan;
+    MsmPlanBase *plan;
+    DevBuf big_in, *in;
+    if (n <= SMALL) {
+        if (!small_plan[group]) {
+            small_plan[group].reset(msm_plan_new(group, SMALL));
+            small_in[group].reset(new DevBuf(SMALL * (32 + PB)));
+        }
+        plan = small_plan[group].get();
+        in = small_in[group].get();
+    } else {
+        big_plan.reset(msm_plan_new(group, n));
+        big_in.alloc(n * (32 + PB));
+        plan = big_plan.get();
+        in = &big_in;
+    }
+    char *ds = in->as<char>(), *dp = ds + n * 32;
+    ZK_HIP(hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(dp, points, n * PB, hipMemcpyHostToDevice));
+    return plan->run_affine(ds, dp, n, out_xy, out_is_inf, 0);
 }
 
 template <class F> static int fold_partials(const uint64_t *partials, size_t count, uint64_t *out_xy, int *out_is_inf) {

@@ -137,8 +137,11 @@ class ScaleCRS:
         hq = [powers[k] * zx % R * dinv % R for k in range(m - 1)]
         s15 = np.zeros((m - 1, 8), dtype=np.uint64)
         _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(hq)), m - 1, _lib.ptr(s15)))
-        self.h_sigma1_2_head = limbs_to_g1(s12[:2])
-        self.d_s12, self.d_s22, self.d_s14, self.d_s15 = _dev(s12), _dev(s22), _dev(s14), _dev(s15)
+        # query arrays with the constant terms appended, so that a proof element is ONE device MSM:
+        #   G1: sigma1_2 | alpha*G1 | delta*G1 | beta*G1        G2: sigma2_2 | beta*G2 | delta*G2
+        s12x = np.concatenate([s12, g1_to_limbs([self.sigma1_1[0], self.sigma1_1[2], self.sigma1_1[1]])])
+        s22x = np.concatenate([s22, g2_to_limbs([self.sigma2_1[0], self.sigma2_1[2]])])
+        self.d_s12, self.d_s22, self.d_s14, self.d_s15 = _dev(s12x), _dev(s22x), _dev(s14), _dev(s15)
 
 
 class ScaleProver:
@@ -150,44 +153,63 @@ class ScaleProver:
         c = crs.circuit
         self.m, self.W = c.m, c.num_wires
         self.ntt = NttPlan(c.log_m)
-        self.g1 = MsmPlan(_lib.GROUP_G1, self.W)
-        self.g2 = MsmPlan(_lib.GROUP_G2, self.m)
-        self.scratch = [torch.empty((self.m, 4), dtype=torch.int64, device="cuda") for _ in range(4)]
+        self.g1 = MsmPlan(_lib.GROUP_G1, max(self.W, self.m + 3))
+        self.g2 = MsmPlan(_lib.GROUP_G2, self.m + 2)
+        new = lambda rows: torch.empty((rows, 4), dtype=torch.int64, device="cuda")
+        self.ext_a, self.ext_b1, self.ext_b2 = new(self.m + 3), new(self.m + 3), new(self.m + 2)
+        self.scratch = [new(self.m) for _ in range(4)]
         self.zinv = pow((pow(COSET_SHIFT, self.m, R) - 1) % R, -1, R)  # 1 / Z_H on the coset k*H
 
     def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
-        """d_a, d_b, d_c: device (m, 4) evaluations sum_i w_i A[k][i] etc.; d_w: device (W, 4) witness.
-        The three evaluation buffers are overwritten with the coefficient vectors u_A, u_B, u_C.
-        -> (proof_A, proof_B, proof_C) as points, plus the H coefficients' device buffer."""
+        """d_a, d_b, d_c: device (m, 4) evaluations sum_i w_i A[k][i] etc. (d_c is overwritten with the
+        coefficient vector u_C); d_w: device (W, 4) witness.
+        -> (proof_A, proof_B, proof_C) as points, plus the device buffer of the H coefficients."""
         import torch
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         m, W, crs = self.m, self.W, self.crs
+        r, s = r % R, s % R
         ca, cb, cc, h = self.scratch
-        # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.)
-        for d in (d_a, d_b, d_c):
+        ua, ub = self.ext_a[:m], self.ext_b1[:m]
+        ua.copy_(d_a)
+        ub.copy_(d_b)
+        # constant-term scalars behind the coefficient vectors (see ScaleCRS): [1, r, 0] / [0, 0, 1] / [1, s]
+        self.ext_a[m:] = _dev(_lib.ints_to_limbs([1, r, 0]))
+        self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
+        self.ext_b2[m:] = _dev(_lib.ints_to_limbs([1, s]))
+        # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.): 3 inverse NTTs
+        for d in (ua, ub, d_c):
             self.ntt.run(d.data_ptr(), True, None, st)
-        # H = (A*B - C) / Z on the coset 5*H
-        ca.copy_(d_a)
-        cb.copy_(d_b)
+        self.ext_b2[:m].copy_(ub)
+        # the three u-dependent MSMs go first; their host folds overlap the H pipeline below
+        t_a = self.g1.submit(self.ext_a.data_ptr(), crs.d_s12.data_ptr(), m + 3, st)     # alpha + A(x) + r*delta
+        t_b2 = self.g2.submit(self.ext_b2.data_ptr(), crs.d_s22.data_ptr(), m + 2, st)   # beta + B(x) + s*delta in G2
+        t_b1 = self.g1.submit(self.ext_b1.data_ptr(), crs.d_s12.data_ptr(), m + 3, st)   # beta + B(x) in G1
+        # H = (A*B - C) / Z on the coset 5*H: 3 coset NTTs + pointwise quotient + 1 coset inverse NTT
+        ca.copy_(ua)
+        cb.copy_(ub)
         cc.copy_(d_c)
         for d in (ca, cb, cc):
             self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
-        # queries
-        msm_a = self.g1.run(d_a.data_ptr(), crs.d_s12.data_ptr(), m, st)
-        msm_b2 = self.g2.run(d_b.data_ptr(), crs.d_s22.data_ptr(), m, st)
-        msm_b1 = self.g1.run(d_b.data_ptr(), crs.d_s12.data_ptr(), m, st)
-        msm_l = self.g1.run(d_w.data_ptr(), crs.d_s14.data_ptr(), W, st)   # placeholders at public wires are infinity
-        msm_h = self.g1.run(h.data_ptr(), crs.d_s15.data_ptr(), m - 1, st)
-        from ..field import msm_g2
-        r, s = r % R, s % R
-        s11, s21 = crs.sigma1_1, crs.sigma2_1
-        proof_a = msm_g1([1, 1, r], [msm_a, s11[0], s11[2]])                      # proving.py:23-33
-        proof_b = msm_g2([1, 1, s], [msm_b2, s21[0], s21[2]])                     # proving.py:35-45
+        proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                          # proving.py:23-33
+        t_l = self.g1.submit(d_w.data_ptr(), crs.d_s14.data_ptr(), W, st)                # placeholders at public wires are infinity
+        msm_b1 = self._pt(self.g1, self.g1.collect_limbs(t_b1))
+        t_h = self.g1.submit(h.data_ptr(), crs.d_s15.data_ptr(), m - 1, st)
+        msm_l = self._pt(self.g1, self.g1.collect_limbs(t_l))
+        msm_h = self._pt(self.g1, self.g1.collect_limbs(t_h))
+        proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                         # proving.py:35-45
         # proving.py:47-75 with the +-r*s*delta terms cancelled:  s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H
-        proof_c = msm_g1([s, r, r, 1, 1], [proof_a, s11[1], msm_b1, msm_l, msm_h])
+        proof_c = msm_g1([s, r, 1, 1], [proof_a, msm_b1, msm_l, msm_h])
         return proof_a, proof_b, proof_c, h
+
+    @staticmethod
+    def _pt(plan, res):
+        limbs, inf = res
+        if inf:
+            return None
+        from ..field import limbs_to_g2
+        return (limbs_to_g1(limbs) if plan.group == _lib.GROUP_G1 else limbs_to_g2(limbs))[0]
 
 
 def closed_form_scalars(crs, witness, r, s):
