@@ -1,8 +1,9 @@
 // host_field.h -- host-only F_p / F_p^2 / F_r arithmetic with 4 x 64-bit limbs (unsigned __int128
-// products), same Montgomery radix 2^256 as the device code, so a device element converts by
-// re-packing limbs.  Used for the O(1)-size host epilogues of the GPU pipelines (window-sum
-// Horner fold of the MSM, multi-GPU partial folding, NTT twiddle-table generation), where a
-// single GPU thread would be latency-bound.  curve.h's templates work on these types unchanged.
+// products), Montgomery radix 2^256.  The device code uses 9 x 29-bit limbs with radix 2^261, so a
+// device element crosses over with one multiplication by a constant (HFe::from_dev / to_dev).
+// Used for the O(1)-size host epilogues of the GPU pipelines (window-sum Horner fold of the MSM,
+// multi-GPU partial folding, NTT twiddle-table generation, the pairing), where a single GPU thread
+// would be latency-bound.  curve.h's templates work on these types unchanged.
 #pragma once
 #include <stdint.h>
 #include <string.h>

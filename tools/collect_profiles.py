@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Collect the measurement artifacts kept under profiles/ (run from the repo root on the GPU box).
+
+    python3 tools/collect_profiles.py run  [--round r01]   # on the GPU box: bench line + rocprofv3 passes -> gpurun_out/prof_<round>/
+    python3 tools/collect_profiles.py fold [--round r01]   # anywhere: gpurun_out/prof_<round>/ -> profiles/<round>_*
+
+`run` starts each program directly after `rocprofv3 ... --` (no shell/env hop) and keeps the
+counter passes (`--pmc`) separate from the kernel trace, one counter per pass."""
+import argparse, csv, glob, json, os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0"]
+
+
+def sh(cmd, log):
+    with open(log, "w") as f:
+        rc = subprocess.call(cmd, stdout=f, stderr=subprocess.STDOUT, cwd=ROOT)
+    print("rc=%d  %s" % (rc, " ".join(cmd)), flush=True)
+    return rc
+
+
+def run(rnd):
+    out = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+    os.makedirs(out, exist_ok=True)
+    env_tmp = os.environ.setdefault("TMPDIR", "/tmp")
+    rc = sh(["python3", "bench.py"], os.path.join(out, "bench_line.log"))
+    if rc:
+        return rc
+    rc = sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "trace"), "--"] + BENCH_QUICK + ["--steps", "10", "--warmup", "2"],
+            os.path.join(out, "trace.log"))
+    if rc:
+        return rc
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        rc = sh(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(out, "pmc_" + ctr), "--"] + BENCH_QUICK + ["--steps", "3", "--warmup", "1"],
+                os.path.join(out, "pmc_%s.log" % ctr))
+        if rc:
+            return rc
+    return 0
+
+
+def short_name(full):
+    m = re.match(r"(?:void )?(?:zk::)?([A-Za-z0-9_]+(?:<.*?>)?)\(", full)
+    return m.group(1) if m else full
+
+
+def fold(rnd):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+    dst = os.path.join(ROOT, "profiles")
+    line = [l for l in open(os.path.join(src, "bench_line.log")) if l.startswith("{")][-1]
+    with open(os.path.join(dst, rnd + "_bench_line.json"), "w") as f:
+        f.write(line)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        with open(stats[0]) as f, open(os.path.join(dst, rnd + "_bench_kernel_stats.csv"), "w") as g:
+            g.write(f.read())
+    rows = []
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for path in glob.glob(os.path.join(src, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True):
+            acc = {}
+            for r in csv.DictReader(open(path)):
+                if r.get("Counter_Name") != ctr:
+                    continue
+                k = short_name(r["Kernel_Name"])
+                a = acc.setdefault(k, {})
+                a[r["Dispatch_Id"]] = a.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            for k, d in sorted(acc.items()):
+                avg = sum(d.values()) / len(d)
+                rows.append((k, ctr, len(d), avg))
+                per.setdefault(k, {})[ctr] = avg
+    with open(os.path.join(dst, rnd + "_pmc_fetch_write_summary.csv"), "w") as f:
+        f.write("kernel,counter,dispatches,avg_value_KB_per_dispatch\n")
+        for k, ctr, n, avg in rows:
+            f.write('"%s",%s,%d,%.1f\n' % (k, ctr, n, avg))
+    acc_k = [k for k in per if k.startswith("msm_accumulate_kernel") and "FpTag" in k and "Fp2" not in k]
+    if acc_k and len(per[acc_k[0]]) == 2:
+        v = per[acc_k[0]]
+        traffic = {"msm_accumulate_g1_2^20": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
+                   "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from two separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_summary.csv); "
+                            "raw reading, no x2 FETCH correction (64-byte gathers, not a 16 B/lane streaming read)" % rnd}
+        with open(os.path.join(dst, "traffic.json"), "w") as f:
+            json.dump(traffic, f, indent=1)
+    print("folded", src, "->", dst)
+    return 0
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("mode", choices=["run", "fold"])
+    ap.add_argument("--round", default="r01")
+    a = ap.parse_args()
+    sys.exit(run(a.round) if a.mode == "run" else fold(a.round))
