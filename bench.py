@@ -17,7 +17,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                 double-and-add + affine add, as zkp/plonk/kzg.py:59-65 does) timed on one host
                 core on a bounded sample of the same workload.
 """
-import argparse
+import argparse, ctypes
 import json
 import os
 import sys
@@ -191,6 +191,42 @@ def main():
                         "algorithmic_GBps": 64.0 * m / (ms * 1e-3) / 1e9, "hbm_frac": 64.0 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "roundtrip_exact": bool(torch.equal(d, ref))}
 
+    # ---- secondary: "witness-like" scalars: half the scalars are 0 or 1, the rest uniform
+    if rank == 0 and world == 1:
+        wrng = np.random.default_rng(0x5EEDB256)
+        wl = scalars.copy()
+        pick = wrng.random(n)
+        wl[pick < 0.25] = 0
+        wl[(pick >= 0.25) & (pick < 0.5)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+        d_wl = torch.from_numpy(wl.view(np.int64)).to(dev)
+        plan.run(d_wl.data_ptr(), d_points.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        wreps = 5
+        for _ in range(wreps):
+            wres = plan.run(d_wl.data_ptr(), d_points.data_ptr(), n, stream)
+        wms = (time.perf_counter() - w0) / wreps * 1e3
+        extra["witness_like"] = {"ms_per_msm_blocking": round(wms, 4), "points_per_s": n / (wms * 1e-3),
+                                 "verified_closed_form": bool(wres == ec_mul(G1, limbs_dot_mod_r(wl, ks))),
+                                 "stage_ms": [round(v, 4) for v in plan.stage_ms()]}
+        del d_wl
+
+    # ---- the integer-ALU ceiling the MSM is really priced against (row D3): this library's own field
+    # multiplication / mixed addition run flat out on the whole chip, measured live
+    alu = None
+    if rank == 0:
+        rate = ctypes.c_double()
+        _lib.check(lib.zk_measure_rate(0, ctypes.byref(rate)))
+        modmul_peak = rate.value
+        _lib.check(lib.zk_measure_rate(1, ctypes.byref(rate)))
+        madd_peak = rate.value
+        W = -(-255 // plan.window_bits(n))
+        madds = float(n) * W  # one mixed addition per (point, window) digit; zero digits (2^-c of them) are skipped
+        acc_s = float(stage[2]) * 1e-3
+        alu = {"unit": "G1 mixed additions/s", "per_launch": madds, "achieved": madds / acc_s if acc_s > 0 else 0.0, "peak": madd_peak,
+               "frac": (madds / acc_s / madd_peak) if acc_s > 0 else 0.0, "modmul_peak_per_s": modmul_peak,
+               "modmul_per_madd": 10, "note": "peak = zk_measure_rate(1): dependent XYZZ+=affine chains, one wave per workgroup, chip oversubscribed"}
+
     # ---- secondary: Groth16 prove() wall-clock on a synthetic 2^20-constraint R1CS (BASELINE.json configs[3])
     if args.groth16_log_m and world == 1:
         try:
@@ -213,10 +249,22 @@ def main():
         cdt = time.perf_counter() - c0
         sub = plan.run(d_scalars.data_ptr(), d_points.data_ptr(), k, stream)
         same = (sub is None and ref_pt is None) or (sub is not None and ref_pt == (int(sub[0]), int(sub[1])))
+        # second CPU line: the oracle's serial bucket-method MSM in C, one core, 2^16-point sample
+        import c_oracle
+        kc = min(1 << 16, n)
+        c1 = time.perf_counter()
+        c_pt = c_oracle.g1_msm_bucket_arr(scalars[:kc], points[:kc], 13)
+        cct = time.perf_counter() - c1
+        sub_c = plan.run(d_scalars.data_ptr(), d_points.data_ptr(), kc, stream)
+        same_c = sub_c is not None and [int(v) for v in sub_c] == _lib.limbs_to_ints(c_pt.reshape(2, 4))
+        compiled = {"value": kc / cct, "unit": "points/s", "cores": 1, "kind": "port",
+                    "sample": "first %d points, oracle/bn254_oracle.c orc_g1_msm_bucket (serial Pippenger, c=13, Jacobian); %.1f s; "
+                              "matches GPU MSM of the same sample: %s" % (kc, cct, same_c)}
         cpu = {"value": k / cdt, "unit": "points/s", "cores": 1, "kind": "port",
                "sample": "first %d points/scalars of the same workload, oracle/py_ref.msm_naive "
                          "(affine double-and-add per term, as zkp/plonk/kzg.py:59-65); %.1f s; matches GPU MSM of the same sample: %s"
-                         % (k, cdt, same)}
+                         % (k, cdt, same),
+               "compiled_c": compiled}
 
     if rank == 0:
         total_points = n * world * args.steps
@@ -239,7 +287,7 @@ def main():
                        "points_per_gpu": n, "sharding": "point chunks, 1 all-gather of 128-B partials" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<Fp>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "integer-ALU-bound kernel: ~160 modular multiplications per point; see DESIGN.md"},
+                         "note": "integer-ALU-bound kernel: ~160 modular multiplications per point; see 'alu' and DESIGN.md", "alu": alu},
             "cpu_baseline": cpu,
             "extra": extra,
         }

@@ -146,6 +146,13 @@ int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scala
 int zk_pairing(const uint64_t g1_xy[8], const uint64_t g2_xy[16], uint64_t out_fq12[48]);
 int zk_pairing_check(const uint64_t *g1_points /* n*8 */, const uint64_t *g2_points /* n*16 */, size_t n, int *out_is_one);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): chip-wide rate of the library's own arithmetic,
+ * the integer-ALU ceiling bench.py prices the MSM against.
+ *   what = 0: Montgomery multiplications in F_p per second;  1: G1 mixed (XYZZ += affine) additions per second.
+ */
+int zk_measure_rate(int what, double *out_per_sec);
+
 #ifdef __cplusplus
 }
 #endif

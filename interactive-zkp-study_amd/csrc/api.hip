@@ -73,6 +73,67 @@ __global__ __launch_bounds__(64) void group_op_kernel(int op, const uint32_t *p,
     store_affine_canonical(out + (size_t)i * PW, xyzz_to_affine(r));
 }
 
+// Arithmetic-rate probes (zk_measure_rate): the integer-ALU ceilings the MSM kernels are priced against.
+// Every thread runs a dependent chain, the grid oversubscribes the chip, so the rate is the chip-wide
+// issue limit of the field multiplication / the mixed addition as compiled into this library.
+__global__ __launch_bounds__(256) void rate_modmul_kernel(Fp *out, int iters, uint32_t sink_thread) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    Fp x = Fp::one(), y = Fp::one();
+    x.l[0] = (x.l[0] + i) & 0x1fffffffu;
+    y.l[1] = (y.l[1] + (i >> 3)) & 0x1fffffffu;
+#pragma unroll 1
+    for (int k = 0; k < iters; k++) {
+        x = fe_mul(x, y);
+        y = fe_mul(y, x);
+    }
+    if (i == sink_thread) out[0] = fe_add(x, y);  // sink_thread is outside the grid: keeps the chain alive, never stores
+}
+__global__ __launch_bounds__(64, 3) void rate_madd_kernel(const uint32_t *gen_xy, Xyzz<Fp> *out, int iters, uint32_t sink_thread) {
+    Affine<Fp> g = load_affine_canonical<Fp>(gen_xy);
+    if (threadIdx.x & 1) g.y = fe_neg<2>(g.y);  // lane-dependent data: keeps the chain on the vector ALU
+    Xyzz<Fp> acc = Xyzz<Fp>::inf();
+#pragma unroll 1
+    for (int k = 0; k < iters; k++) xyzz_add_affine(acc, g);
+    if (blockIdx.x * 64 + threadIdx.x == sink_thread) out[0] = acc;
+}
+
+static int measure_rate(int what, double *out_per_sec) {
+    if (!out_per_sec) return invalid("zk_measure_rate: null output");
+    const int iters = what == 0 ? 512 : 96;
+    DevBuf sink(sizeof(Xyzz<Fp>)), gen(64);
+    const uint64_t g[8] = {1, 0, 0, 0, 2, 0, 0, 0};
+    ZK_HIP(hipMemcpy(gen.p, g, 64, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    ZK_HIP(hipEventCreate(&e0));
+    ZK_HIP(hipEventCreate(&e1));
+    double units = 0;
+    auto launch = [&]() {
+        if (what == 0) {
+            const unsigned blocks = 256 * 16;
+            hipLaunchKernelGGL(rate_modmul_kernel, dim3(blocks), dim3(256), 0, 0, sink.as<Fp>(), iters, 0xffffffffu);
+            units = (double)blocks * 256 * iters * 2;
+        } else {
+            const unsigned blocks = 256 * 4 * 12;  // the accumulate kernel's shape: one wave per workgroup
+            hipLaunchKernelGGL(rate_madd_kernel, dim3(blocks), dim3(64), 0, 0, gen.as<uint32_t>(), sink.as<Xyzz<Fp>>(), iters, 0xffffffffu);
+            units = (double)blocks * 64 * iters;
+        }
+    };
+    launch();
+    ZK_HIP(hipDeviceSynchronize());
+    const int reps = 3;
+    ZK_HIP(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; r++) launch();
+    ZK_HIP(hipEventRecord(e1, 0));
+    ZK_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    ZK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ZK_HIP(hipGetLastError());
+    *out_per_sec = units * reps / (ms * 1e-3);
+    return ZK_OK;
+}
+
 template <class F> static int group_op_host(int op, const uint64_t *p, const uint64_t *q, size_t n, uint64_t *out) {
     constexpr size_t PB = 8 * F::CANON_WORDS;  // bytes of one canonical affine point
     if (n == 0) return ZK_OK;
@@ -269,6 +330,15 @@ int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t
         return group_op_host<Fp2>(2, base_xy, scalars, n, out_points);
     });
 }
+int zk_measure_rate(int what, double *out_per_sec) {
+    return guarded([&]() -> int {
+        int rc = require_device();
+        if (rc) return rc;
+        if (what != 0 && what != 1) return invalid("zk_measure_rate: what must be 0 (F_p multiplications) or 1 (G1 mixed additions)");
+        return measure_rate(what, out_per_sec);
+    });
+}
+
 int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scalar, size_t n, uint64_t *out) {
     return guarded([&] {
         if ((n && (!p || !q_or_scalar || !out)) || (op != 0 && op != 1)) return invalid("zk_group_op: bad argument");

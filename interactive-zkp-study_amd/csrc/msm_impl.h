@@ -111,6 +111,9 @@ constexpr int SEG_NT = 256;
 constexpr int SEG_EPT = 16;  // entries per thread per chunk
 constexpr int SEG_CHUNK = SEG_NT * SEG_EPT;
 constexpr int SIZE_BINS = 1024;  // list lengths >= SIZE_BINS-1 share the top bin
+constexpr int SEG_Z = 8;         // workgroups sharing one cell (they split its chunks round-robin)
+constexpr int HEAVY_SEG = 32;    // entries per heavy-bucket segment (one thread each)
+constexpr int HEAVY_WAVE = 64 * HEAVY_SEG;  // entries per wavefront task
 
 struct SortBufs {
     uint32_t *counts;       // [W*nb]   list length of every bucket
@@ -122,13 +125,14 @@ struct SortBufs {
     uint32_t *e_idx;        // [W*n]    partitioned entries: point index | sign << 31
     uint8_t *e_loc;         // [W*n]    partitioned entries: bucket index inside the cell
     uint32_t *sorted;       // [W*n]    entries grouped by bucket
+    uint32_t *zcount;       // [cells][SEG_Z][SEG_BUCKETS] per-workgroup bucket counts of the two-kernel cell sort
     uint32_t *size_hist;    // [SIZE_BINS] buckets per list length (zeroed by the scan kernel after use)
     uint32_t *size_base;    // [SIZE_BINS] first rank of each length, longest first
     uint32_t *size_cursor;  // [SIZE_BINS] running reservation (zeroed by the scan kernel)
     uint32_t *perm;         // [W*nb]   bucket ids ordered by decreasing list length
     // Heavy buckets (list longer than heavy_th: skewed / witness-like scalars, degenerate top window):
-    // their lists are cut into segments of heavy_th entries, one thread per segment, partials combined
-    // by one wavefront per bucket.  They take rank "length 0" in perm[] so the main kernel skips them.
+    // their lists are cut into segments of HEAVY_SEG entries, one thread per segment, partials combined
+    // by one workgroup per bucket.  They take rank "length 0" in perm[] so the main kernel skips them.
     uint32_t heavy_th;
     uint32_t heavy_cap;     // capacity of heavy_tasks / heavy_buckets (entries)
     uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
@@ -215,7 +219,9 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(SortBufs B, uint32_t nce
     if (!SIZES) {
         const uint32_t v0 = 2 * t < ncells ? B.cell_total[2 * t] : 0u;
         const uint32_t v1 = 2 * t + 1 < ncells ? B.cell_total[2 * t + 1] : 0u;
-        const uint32_t ex = block_exclusive_scan<1024>(v0 + v1, wave_tot, &total);
+        // cell spans start on 16-entry boundaries so the cell sort can fetch 16 entries per load
+        const uint32_t p0 = (v0 + 15u) & ~15u, p1 = (v1 + 15u) & ~15u;
+        const uint32_t ex = block_exclusive_scan<1024>(p0 + p1, wave_tot, &total);
         if (2 * t < ncells) {
             B.cell_base[2 * t] = ex;
             B.cell_cnt[2 * t] = v0;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(SortBufs B, uint32_t nce
             B.cell_cursor[2 * t] = 0;
         }
         if (2 * t + 1 < ncells) {
-            B.cell_base[2 * t + 1] = ex + v0;
+            B.cell_base[2 * t + 1] = ex + p0;
             B.cell_cnt[2 * t + 1] = v1;
             B.cell_total[2 * t + 1] = 0;
             B.cell_cursor[2 * t + 1] = 0;
@@ -254,6 +260,9 @@ __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *_
     __shared__ uint8_t stage_cell[NE];
     const uint32_t t = threadIdx.x;
     const uint32_t i0 = blockIdx.x * NE + t;
+    int nxt[PREP_PPT];
+#pragma unroll
+    for (int rep = 0; rep < PREP_PPT; rep++) nxt[rep] = digits[i0 + rep * PREP_NT];
     for (uint32_t w = 0; w < W; w++) {
         if (t < 128) hist[t] = 0;
         __syncthreads();
@@ -261,7 +270,8 @@ __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *_
         int dd[PREP_PPT];
 #pragma unroll
         for (int rep = 0; rep < PREP_PPT; rep++) {
-            dd[rep] = digits[(size_t)w * n_pad + i0 + rep * PREP_NT];
+            dd[rep] = nxt[rep];
+            if (w + 1 < W) nxt[rep] = digits[(size_t)(w + 1) * n_pad + i0 + rep * PREP_NT];  // in flight during this window's ranking
             jj[rep] = (uint32_t)(dd[rep] < 0 ? -dd[rep] : dd[rep]) - 1u;
             rk[rep] = dd[rep] != 0 ? atomicAdd(&hist[jj[rep] >> SEG_LOG], 1u) : 0u;
         }
@@ -295,62 +305,106 @@ __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *_
     }
 }
 
-// grid = (G, W): one workgroup per cell.
+// Cell sort, grid = (SEG_Z, G, W): up to SEG_Z workgroups share a cell and take its 4096-entry chunks
+// round-robin, so a cell swollen by skewed scalars (a hot digit) is still sorted by several CUs.
+// Kernel 1 counts: zcount[cell][z][b] = entries of bucket b in the chunks of workgroup z.
 template <int DUMMY>
-__global__ __launch_bounds__(SEG_NT) void msm_segsort_kernel(SortBufs B, uint32_t nb) {
+__global__ __launch_bounds__(SEG_NT) void msm_segcount_kernel(SortBufs B) {
+    __shared__ uint32_t hist[SEG_BUCKETS];
+    const uint32_t t = threadIdx.x, z = blockIdx.x, g = blockIdx.y, w = blockIdx.z, G = gridDim.y;
+    const uint32_t cellid = w * G + g;
+    const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
+    const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
+    if (z >= nchunks) return;
+    const uint8_t *__restrict__ loc = B.e_loc + seg0;
+    hist[t] = 0;
+    __syncthreads();
+    for (uint32_t ch = z; ch < nchunks; ch += SEG_Z) {
+        const uint32_t c0 = ch * SEG_CHUNK, cn = min((uint32_t)SEG_CHUNK, seg_n - c0);
+        if (SEG_EPT * t < cn) {
+            const uint4 lv = *reinterpret_cast<const uint4 *>(loc + c0 + SEG_EPT * t);  // thread t owns entries 16t .. 16t+15
+            const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+            for (int k = 0; k < SEG_EPT; k++)
+                if (SEG_EPT * t + k < cn) atomicAdd(&hist[(lw[k >> 2] >> (8 * (k & 3))) & 0xffu], 1u);
+        }
+    }
+    __syncthreads();
+    B.zcount[((size_t)cellid * SEG_Z + z) * SEG_BUCKETS + t] = hist[t];
+}
+
+// Kernel 2 scatters: bucket starts from the summed counts (workgroup 0 of the cell also publishes
+// counts / bucket_off / the list-length histogram), then every workgroup sorts its chunks in LDS
+// (LDS-atomic ranks, block scan, staging buffer) and writes them out as per-bucket runs behind the
+// runs of the workgroups before it.  The order inside a bucket is irrelevant to the sum.
+template <int DUMMY>
+__global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint32_t nb) {
     __shared__ uint32_t cur[SEG_BUCKETS];      // running global write position of every bucket
     __shared__ uint32_t ch_hist[SEG_BUCKETS];  // per-chunk: entries per bucket, then exclusive offsets
     __shared__ uint32_t hist[SIZE_BINS];
     __shared__ uint32_t wave_tot[SEG_NT / 64 + 1];
     __shared__ uint32_t stage_idx[SEG_CHUNK];
     __shared__ uint8_t stage_loc[SEG_CHUNK];
-    const uint32_t t = threadIdx.x, g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+    const uint32_t t = threadIdx.x, z = blockIdx.x, g = blockIdx.y, w = blockIdx.z, G = gridDim.y;
     const uint32_t cellid = w * G + g;
     const uint32_t base = g * SEG_BUCKETS;
     const uint32_t nloc = min((uint32_t)SEG_BUCKETS, nb - base);
     const size_t flat0 = (size_t)w * nb + base;
     const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
+    const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
+    const uint32_t active = min((uint32_t)SEG_Z, nchunks);
+    if (z >= max(active, 1u)) return;  // workgroup 0 always runs: empty cells still publish their zero counts
     const uint8_t *__restrict__ loc = B.e_loc + seg0;
     const uint32_t *__restrict__ idx = B.e_idx + seg0;
     uint32_t *__restrict__ sorted = B.sorted;
 
-    // pass 1: bucket counts of the whole segment
-    cur[t] = 0;
-    for (uint32_t k = t; k < SIZE_BINS; k += SEG_NT) hist[k] = 0;
-    __syncthreads();
-    for (uint32_t v = t; v < seg_n; v += SEG_NT) atomicAdd(&cur[loc[v]], 1u);
-    __syncthreads();
-    const uint32_t c = cur[t];
+    uint32_t c = 0, before = 0;
+    for (uint32_t zz = 0; zz < active; zz++) {
+        const uint32_t v = B.zcount[((size_t)cellid * SEG_Z + zz) * SEG_BUCKETS + t];
+        if (zz < z) before += v;
+        c += v;
+    }
     uint32_t total;
     const uint32_t ex = block_exclusive_scan<SEG_NT>(c, wave_tot, &total);
-    if (t < nloc) {
-        B.counts[flat0 + t] = c;
-        B.bucket_off[flat0 + t] = seg0 + ex;
-        atomicAdd(&hist[size_bin(c, B.heavy_th)], 1u);
+    cur[t] = seg0 + ex + before;
+    if (z == 0) {
+        for (uint32_t k = t; k < SIZE_BINS; k += SEG_NT) hist[k] = 0;
+        __syncthreads();
+        if (t < nloc) {
+            B.counts[flat0 + t] = c;
+            B.bucket_off[flat0 + t] = seg0 + ex;
+            atomicAdd(&hist[size_bin(c, B.heavy_th)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t k = t; k < SIZE_BINS; k += SEG_NT) {
+            const uint32_t h = hist[k];
+            if (h) atomicAdd(&B.size_hist[k], h);
+        }
     }
-    cur[t] = seg0 + ex;
     __syncthreads();
-    for (uint32_t k = t; k < SIZE_BINS; k += SEG_NT) {
-        const uint32_t h = hist[k];
-        if (h) atomicAdd(&B.size_hist[k], h);
-    }
 
-    // pass 2: chunk-wise LDS counting sort, written out as per-bucket runs
-    for (uint32_t c0 = 0; c0 < seg_n; c0 += SEG_CHUNK) {
-        const uint32_t cn = min((uint32_t)SEG_CHUNK, seg_n - c0);
+    for (uint32_t ch = z; ch < nchunks; ch += SEG_Z) {
+        const uint32_t c0 = ch * SEG_CHUNK, cn = min((uint32_t)SEG_CHUNK, seg_n - c0);
         ch_hist[t] = 0;
         __syncthreads();
+        // thread t owns entries 16t .. 16t+15 of the chunk: five 16-byte loads in flight, then the LDS ranks
         uint32_t e_i[SEG_EPT], e_r[SEG_EPT];
         uint8_t e_l[SEG_EPT];
+        if (SEG_EPT * t < cn) {
+            const uint4 lv = *reinterpret_cast<const uint4 *>(loc + c0 + SEG_EPT * t);
+            const uint4 *ip = reinterpret_cast<const uint4 *>(idx + c0 + SEG_EPT * t);
+            const uint4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];
+            const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+            const uint32_t iw[SEG_EPT] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w};
 #pragma unroll
-        for (int k = 0; k < SEG_EPT; k++) {
-            const uint32_t v = k * SEG_NT + t;
-            if (v < cn) {
-                e_l[k] = loc[c0 + v];
-                e_i[k] = idx[c0 + v];
-                e_r[k] = atomicAdd(&ch_hist[e_l[k]], 1u);
+            for (int k = 0; k < SEG_EPT; k++) {
+                e_l[k] = (uint8_t)((lw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                e_i[k] = iw[k];
             }
         }
+#pragma unroll
+        for (int k = 0; k < SEG_EPT; k++)
+            if (SEG_EPT * t + k < cn) e_r[k] = atomicAdd(&ch_hist[e_l[k]], 1u);
         __syncthreads();
         const uint32_t hc = ch_hist[t];
         const uint32_t hx = block_exclusive_scan<SEG_NT>(hc, wave_tot, &total);
@@ -358,8 +412,7 @@ __global__ __launch_bounds__(SEG_NT) void msm_segsort_kernel(SortBufs B, uint32_
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < SEG_EPT; k++) {
-            const uint32_t v = k * SEG_NT + t;
-            if (v < cn) {
+            if (SEG_EPT * t + k < cn) {
                 const uint32_t p = ch_hist[e_l[k]] + e_r[k];
                 stage_idx[p] = e_i[k];
                 stage_loc[p] = e_l[k];
@@ -378,7 +431,7 @@ __global__ __launch_bounds__(SEG_NT) void msm_segsort_kernel(SortBufs B, uint32_
 
 // grid covers the flattened bucket array, 2 buckets per thread: ranks the buckets by list length
 // (workgroup-local LDS histogram, one global reservation per non-empty length bin) and registers
-// heavy buckets with one task per heavy_th-entry segment of their list.
+// heavy buckets (their segment tasks are written by msm_heavy_expand_kernel).
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbuckets) {
     __shared__ uint32_t hist[SIZE_BINS];
@@ -394,13 +447,11 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbu
         if (b0i + q < nbuckets) {
             r[q] = atomicAdd(&hist[bin[q]], 1u);
             if (cc[q] > B.heavy_th) {
-                const uint32_t nseg = (cc[q] + B.heavy_th - 1) / B.heavy_th;
+                const uint32_t nseg = (cc[q] + HEAVY_WAVE - 1) / HEAVY_WAVE;  // wavefront tasks of 64 segments
                 const uint32_t tpos = atomicAdd(&B.heavy_ctr[0], nseg);
                 const uint32_t hb = atomicAdd(&B.heavy_ctr[1], 1u);
-                if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) {  // capacity is sized so this always holds
-                    B.heavy_buckets[hb] = make_uint4(b0i + q, tpos, nseg, 0u);
-                    for (uint32_t k = 0; k < nseg; k++) B.heavy_tasks[tpos + k] = make_uint2(b0i + q, k);
-                }
+                // capacity is sized so this always holds; an unregistered bucket would be caught by the closed-form tests
+                if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) B.heavy_buckets[hb] = make_uint4(b0i + q, tpos, nseg, 0u);
             }
         }
     }
@@ -457,15 +508,14 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumul
     buckets[b] = sum_list(pts, sorted + bucket_off[b], len);
 }
 
-// Heavy buckets, stage 1: one thread per (bucket, segment) task -> partial sums.
-template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_heavy_segments_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B,
-                                                                                            Xyzz<F> *__restrict__ partial) {
-    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= min(B.heavy_ctr[0], B.heavy_cap)) return;
-    const uint2 task = B.heavy_tasks[t];
-    const uint32_t len = B.counts[task.x], lo = task.y * B.heavy_th;
-    partial[t] = sum_list(pts, B.sorted + B.bucket_off[task.x] + lo, min(B.heavy_th, len - lo));
+// Heavy buckets, stage 0: write the (bucket, segment) task list, one workgroup per heavy bucket at a time.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void msm_heavy_expand_kernel(SortBufs B) {
+    const uint32_t nheavy = min(B.heavy_ctr[1], B.heavy_cap);
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint4 hb = B.heavy_buckets[h];
+        for (uint32_t k = threadIdx.x; k < hb.z; k += 256) B.heavy_tasks[hb.y + k] = make_uint2(hb.x, k);
+    }
 }
 
 template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
@@ -477,15 +527,36 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<
     for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
     return r;
 }
-// Heavy buckets, stage 2: one wavefront per bucket; lanes sum the partials serially with stride 64,
-// then a wavefront __shfl tree leaves the bucket sum in lane 0.
+// Heavy buckets, stage 1: one wavefront per task = 64 consecutive HEAVY_SEG-entry segments of one bucket's
+// list; every lane sums its segment, a __shfl tree leaves the task's partial sum in lane 0.
 template <class F>
-__global__ __launch_bounds__(64) void msm_heavy_combine_kernel(SortBufs B, const Xyzz<F> *__restrict__ partial, Xyzz<F> *__restrict__ buckets) {
-    const uint32_t nheavy = min(B.heavy_ctr[1], B.heavy_cap), lane = threadIdx.x;
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_heavy_segments_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B,
+                                                                                            Xyzz<F> *__restrict__ partial) {
+    const uint32_t ntasks = min(B.heavy_ctr[0], B.heavy_cap), lane = threadIdx.x;
+    for (uint32_t wt = blockIdx.x; wt < ntasks; wt += gridDim.x) {
+        const uint2 task = B.heavy_tasks[wt];
+        const uint32_t len = B.counts[task.x], lo = (task.y * 64 + lane) * HEAVY_SEG;
+        Xyzz<F> acc = sum_list(pts, B.sorted + B.bucket_off[task.x] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u);
+#pragma unroll 1
+        for (int d = 32; d >= 1; d >>= 1) {
+            const Xyzz<F> o = shfl_down_xyzz(acc, d);
+            xyzz_add(acc, o);
+        }
+        if (lane == 0) partial[wt] = acc;
+    }
+}
+
+// Heavy buckets, stage 2: one 512-thread workgroup per bucket; threads sum the partials serially with
+// stride 512, then a wavefront __shfl tree, an 8-entry LDS exchange and a second tree in wavefront 0.
+constexpr int HEAVY_CT = 512;
+template <class F>
+__global__ __launch_bounds__(HEAVY_CT) void msm_heavy_combine_kernel(SortBufs B, const Xyzz<F> *__restrict__ partial, Xyzz<F> *__restrict__ buckets) {
+    __shared__ Xyzz<F> wave_sum[HEAVY_CT / 64];
+    const uint32_t nheavy = min(B.heavy_ctr[1], B.heavy_cap), t = threadIdx.x;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const uint4 hb = B.heavy_buckets[h];
         Xyzz<F> acc = Xyzz<F>::inf();
-        for (uint32_t k = lane; k < hb.z; k += 64) {
+        for (uint32_t k = t; k < hb.z; k += HEAVY_CT) {
             const Xyzz<F> v = partial[hb.y + k];
             xyzz_add(acc, v);
         }
@@ -494,7 +565,18 @@ __global__ __launch_bounds__(64) void msm_heavy_combine_kernel(SortBufs B, const
             const Xyzz<F> o = shfl_down_xyzz(acc, d);
             xyzz_add(acc, o);
         }
-        if (lane == 0) buckets[hb.x] = acc;
+        if ((t & 63) == 0) wave_sum[t >> 6] = acc;
+        __syncthreads();
+        if (t < 64) {
+            acc = t < HEAVY_CT / 64 ? wave_sum[t] : Xyzz<F>::inf();
+#pragma unroll 1
+            for (int d = HEAVY_CT / 128; d >= 1; d >>= 1) {
+                const Xyzz<F> o = shfl_down_xyzz(acc, d);
+                xyzz_add(acc, o);
+            }
+            if (t == 0) buckets[hb.x] = acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -588,8 +670,11 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
+    DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, zcount, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
     uint32_t heavy_cap = 0;
+    // heavy buckets are summed on a second stream, beside the main accumulate kernel
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Two submissions may be in flight: the 36 KiB read-back buffer, its completion event and the
     // profiling events are per slot, everything else is reused in stream order.
     static constexpr int SLOTS = 2;
@@ -618,17 +703,23 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             outn = std::max(outn, W * (size_t)c * sizeof(Xyzz<F>));
         }
         digits.alloc(dig);
-        sorted.alloc(dig * 2);  // one 4-byte entry per (window, point)
+        const size_t span_slack = (size_t)MAX_CELLS * 16 + 64;  // cell spans are padded to 16 entries
+        sorted.alloc(dig * 2 + span_slack * 4);  // one 4-byte entry per (window, point)
         counts.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
         bucket_off.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
-        e_idx.alloc(dig * 2);
-        e_loc.alloc(dig / 2);
+        e_idx.alloc(dig * 2 + span_slack * 4);
+        e_loc.alloc(dig / 2 + span_slack);
         cells.alloc(4 * MAX_CELLS * sizeof(uint32_t));  // cell_total | cell_base | cell_cnt | cell_cursor
         ZK_HIP(hipMemset(cells.p, 0, 4 * MAX_CELLS * sizeof(uint32_t)));
         size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
         ZK_HIP(hipMemset(size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
-        // heavy-bucket scratch: tasks <= 2*n*W/heavy_th with heavy_th = max(32, 8n/nb), i.e. <= W*nb/2 (with room)
-        heavy_cap = (uint32_t)(ar / sizeof(Xyzz<F>) / 2 + 64);
+        zcount.alloc((size_t)MAX_CELLS * SEG_Z * SEG_BUCKETS * sizeof(uint32_t));
+        // heavy-bucket scratch: a heavy bucket holds > heavy_th >= HEAVY_SEG entries, so there are < entries / HEAVY_SEG of
+        // them and sum ceil(len / HEAVY_WAVE) <= entries / HEAVY_WAVE + (heavy buckets) wavefront tasks; entries <= W * n_pad
+        heavy_cap = (uint32_t)(dig / sizeof(int16_t) / HEAVY_SEG + dig / sizeof(int16_t) / HEAVY_WAVE + 64);
+        ZK_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        ZK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        ZK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         heavy_tasks.alloc((size_t)heavy_cap * sizeof(uint2));
         heavy_buckets.alloc((size_t)heavy_cap * sizeof(uint4));
         heavy_partial.alloc((size_t)heavy_cap * sizeof(Xyzz<F>));
@@ -638,6 +729,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         for (auto &sl : slots) sl.h_out.alloc(outn);
     }
     ~MsmPlanImpl() override {
+        if (aux) (void)hipStreamDestroy(aux);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         for (auto &sl : slots) {
             if (sl.done) (void)hipEventDestroy(sl.done);
             for (auto &e : sl.ev)
@@ -671,6 +765,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.e_idx = e_idx.as<uint32_t>();
         B.e_loc = e_loc.as<uint8_t>();
         B.sorted = sorted.as<uint32_t>();
+        B.zcount = zcount.as<uint32_t>();
         B.size_hist = size_bins.as<uint32_t>();
         B.size_base = B.size_hist + SIZE_BINS;
         B.size_cursor = B.size_hist + 2 * SIZE_BINS;
@@ -683,19 +778,24 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const uint32_t nbuckets_all = W * nb;
         hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, digits.as<int16_t>(), B, n_pad, W, G);
-        hipLaunchKernelGGL((msm_segsort_kernel<0>), dim3(G, W), dim3(SEG_NT), 0, st, B, nb);
+        hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B);
+        hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B, nb);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((nbuckets_all + 2047) / 2048), dim3(1024), 0, st, B, nbuckets_all);
         mark(2, st);
+        // heavy buckets (normally none) on the aux stream: the grids cover the worst case and exit on the device-side counters
+        ZK_HIP(hipEventRecord(ev_fork, st));
+        ZK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+        hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, aux, B);
+        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, aux, pts_m.as<PackedAffine<F>>(), B,
+                           heavy_partial.as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, aux, B, heavy_partial.as<Xyzz<F>>(), arena.as<Xyzz<F>>());
+        ZK_HIP(hipEventRecord(ev_join, aux));
         const uint32_t nbuckets = W * nb;
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(),
                            sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), perm.as<uint32_t>(),
                            arena.as<Xyzz<F>>(), nbuckets, B.heavy_th);
-        // heavy buckets (normally none): the grids cover the worst case and exit on the device-side counters
-        const uint32_t max_tasks = std::min<uint32_t>(heavy_cap, 2 * (uint32_t)(((size_t)n_pad * W) / B.heavy_th) + 64);
-        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3((max_tasks + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(), B,
-                           heavy_partial.as<Xyzz<F>>());
-        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(std::min<uint32_t>(max_tasks, 1024)), dim3(64), 0, st, B, heavy_partial.as<Xyzz<F>>(), arena.as<Xyzz<F>>());
+        ZK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     }
 
     // Enqueues the whole GPU pipeline plus the 36 KiB read-back on `st`; returns a ticket.

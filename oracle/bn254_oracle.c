@@ -350,6 +350,47 @@ void orc_g2_msm(const uint64_t *scalars, const uint64_t *points, size_t n, uint6
     g2_store(out, &acc);
 }
 
+/* Bucket-method (Pippenger) G1 MSM, unsigned c-bit windows -- the textbook algorithm, serial, used as
+ * (i) a second, structurally different checker for large inputs where orc_g1_msm is too slow and
+ * (ii) bench.py's "compiled C, one core" CPU line.  Same group element as orc_g1_msm. */
+static unsigned window_digit(const uint64_t k[4], unsigned lo, unsigned c) {
+    unsigned word = lo >> 6, off = lo & 63;
+    uint64_t v = k[word] >> off;
+    if (off + c > 64 && word < 3) v |= k[word + 1] << (64 - off);
+    return (unsigned)(v & ((1ULL << c) - 1));
+}
+int orc_g1_msm_bucket(const uint64_t *scalars, const uint64_t *points, size_t n, unsigned c, uint64_t out[8]) {
+    ensure_init();
+    if (c < 1 || c > 20) return -1;
+    const unsigned windows = (254 + c - 1) / c;
+    const size_t nb = ((size_t)1 << c) - 1;
+    g1_jac *buckets = (g1_jac *)malloc(sizeof(g1_jac) * nb);
+    g1_jac *pts = (g1_jac *)malloc(sizeof(g1_jac) * (n ? n : 1));
+    if (!buckets || !pts) { free(buckets); free(pts); return -2; }
+    for (size_t i = 0; i < n; i++) g1_load(&pts[i], points + 8 * i);
+    g1_jac total, run, wsum;
+    memset(&total, 0, sizeof(total));
+    for (int w = (int)windows - 1; w >= 0; w--) {
+        for (unsigned d = 0; d < c; d++) g1_dbl(&total, &total);
+        memset(buckets, 0, sizeof(g1_jac) * nb);
+        for (size_t i = 0; i < n; i++) {
+            unsigned d = window_digit(scalars + 4 * i, (unsigned)w * c, c);
+            if (d) g1_add(&buckets[d - 1], &buckets[d - 1], &pts[i]);
+        }
+        memset(&run, 0, sizeof(run));
+        memset(&wsum, 0, sizeof(wsum));
+        for (size_t b = nb; b-- > 0;) {       /* sum_b (b+1) * bucket[b] by running sums */
+            g1_add(&run, &run, &buckets[b]);
+            g1_add(&wsum, &wsum, &run);
+        }
+        g1_add(&total, &total, &wsum);
+    }
+    g1_store(out, &total);
+    free(buckets);
+    free(pts);
+    return 0;
+}
+
 /* Fixed-base batch: out[i] = k_i * P  (SRS.generate zkp/plonk/srs.py:77-82, sigma12 setup.py:18-23) */
 void orc_g1_fixed_base(const uint64_t p[8], const uint64_t *scalars, size_t n, uint64_t *out) {
     for (size_t i = 0; i < n; i++) orc_g1_mul(p, scalars + 4 * i, out + 8 * i);

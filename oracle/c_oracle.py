@@ -115,6 +115,17 @@ def g1_msm_arr(scalars, points):
     return O
 
 
+def g1_msm_bucket_arr(scalars, points, c=12):
+    """Bucket-method MSM (orc_g1_msm_bucket), same result as g1_msm_arr; c = window bits."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    O = np.zeros(8, dtype=np.uint64)
+    rc = lib().orc_g1_msm_bucket(_p(scalars), _p(points), ctypes.c_size_t(scalars.shape[0]), ctypes.c_uint(c), _p(O))
+    if rc:
+        raise RuntimeError("orc_g1_msm_bucket failed: %d" % rc)
+    return O
+
+
 def g2_msm_arr(scalars, points):
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
     points = np.ascontiguousarray(points, dtype=np.uint64)

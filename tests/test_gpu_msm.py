@@ -181,6 +181,32 @@ def test_g1_msm_2pow16_bit_exact():
     assert np.array_equal(msm_g1(S, Pts), co.g1_msm_arr(S, Pts))
 
 
+@pytest.mark.parametrize("pattern", ["witness_like", "all_equal", "two_values", "minus_one_heavy"])
+def test_g1_msm_skewed_scalars_large(pattern):
+    """Hot digits at 2^18 points: cells far larger than one workgroup's share and buckets with up to n entries
+    (multi-workgroup cell sort, heavy-bucket wavefront tasks) -- bit-exact against the oracle's serial bucket MSM."""
+    from bench import random_scalars
+    rng = np.random.default_rng(4242)
+    n = (1 << 18) + 77
+    K = random_scalars(rng, n)
+    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+    Pts = np.zeros((n, 8), dtype=np.uint64)
+    _lib.check(_lib.load().zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(K), n, _lib.ptr(Pts)))
+    S = random_scalars(rng, n)
+    pick = rng.random(n)
+    if pattern == "witness_like":
+        S[pick < 0.25] = 0
+        S[(pick >= 0.25) & (pick < 0.5)] = limb_row(1)
+    elif pattern == "all_equal":
+        S[:] = S[0]
+    elif pattern == "two_values":
+        S[pick < 0.5] = S[0]
+        S[pick >= 0.5] = S[1]
+    else:
+        S[pick < 0.7] = limb_row(o.R - 1)
+    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_bucket_arr(S, Pts, 14))
+
+
 @pytest.mark.parametrize("n", [131072, 131073, 300001])
 def test_g1_msm_closed_form_across_c16_switch(n):
     """P_i = k_i*G1 (generated on the GPU, spot-checked against the oracle): MSM = (sum s_i k_i) * G1."""

@@ -213,3 +213,20 @@ def test_c_oracle_ntt_sizes():
     assert np.array_equal(co.ntt_arr(y, w, inverse=True), x)
     for i in (0, 1, 77, 4095):
         assert co.from_limbs(y[i:i + 1])[0] == co.fr_horner_arr(x, pow(w, i, R))
+
+
+def test_c_oracle_bucket_msm_matches_naive():
+    """orc_g1_msm_bucket (serial Pippenger) == orc_g1_msm (per-term double-and-add) for several window widths."""
+    rng = np.random.default_rng(77)
+    n = 200
+    sc = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, o.R - 1, 1
+    ks = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)]
+    P = co.g1_fixed_base_arr(o.G1, co.to_limbs(ks))
+    P[5] = 0                      # infinity input
+    P[7] = P[6]                   # duplicate point
+    S = co.to_limbs(sc)
+    want = co.g1_msm_arr(S, P)
+    for c in (1, 4, 11, 16):
+        assert (co.g1_msm_bucket_arr(S, P, c) == want).all()
+    assert (co.g1_msm_bucket_arr(S[:0], P[:0], 8) == 0).all()
