@@ -51,10 +51,12 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
 // R butterfly stages (s_hi .. s_hi-R+1) on 2^R elements held in registers: LDS is read and written
 // once per element per round instead of once per stage, and a stage's twiddle is fetched once per
 // 2^(R-1-b) butterflies.  Values stay < 2r (see the pass kernel).
-template <int R>
+// LAST: the round that ends at stage 0 (s_lo == 0): there `low` is 0, so every q == 0 twiddle is w^0 = 1
+// and those butterflies skip the multiplication (all of stage 0, half of stage 1, a quarter of stage 2).
+template <int R, bool LAST>
 __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, uint32_t tile, uint32_t ntw, uint32_t lp, uint32_t g,
                                           int s_hi) {
-    const int s_lo = s_hi - R + 1;
+    const int s_lo = LAST ? 0 : s_hi - R + 1;
     const uint32_t ngroups = tile >> R;
     for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NTT_NT) {
         const uint32_t c = gi & ((1u << g) - 1u), rest = gi >> g;
@@ -68,13 +70,20 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
             const int s = s_lo + b;
 #pragma unroll
             for (int q = 0; q < (1 << b); q++) {
-                const Fr w = lds_ld(tw, ntw, (low | ((uint32_t)q << s_lo)) << (lp - 1 - s));
+                const bool unit = LAST && q == 0;
+                Fr w;
+                if (!unit) w = lds_ld(tw, ntw, (low | ((uint32_t)q << s_lo)) << (lp - 1 - s));
 #pragma unroll
                 for (int hi = 0; hi < (1 << (R - 1 - b)); hi++) {
                     const int k0 = (hi << (b + 1)) | q, k1 = k0 | (1 << b);
                     Fr sum = fe_add(x[k0], x[k1]);  // < 4r
                     fe_wreduce<4>(sum);             // < 2r
-                    x[k1] = fe_mul(fe_sub_k<2>(x[k0], x[k1]), w);  // (a - b + 2r) < 4r, w < r  ->  < 2r
+                    Fr dif = fe_sub_k<2>(x[k0], x[k1]);  // (a - b + 2r) < 4r
+                    if (unit)
+                        fe_wreduce<4>(dif);         // < 2r
+                    else
+                        dif = fe_mul(dif, w);       // w < r  ->  < 2r
+                    x[k1] = dif;
                     x[k0] = sum;
                 }
             }
@@ -133,12 +142,16 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     for (int sh = (int)lp - 1; sh >= 0;) {
         const int rem = sh + 1;
         const int R = (rem >= 5 || rem == 3) ? 3 : (rem == 1 ? 1 : 2);
-        if (R == 3)
-            ntt_round<3>(data, tw, tile, ntw, lp, g, sh);
-        else if (R == 2)
-            ntt_round<2>(data, tw, tile, ntw, lp, g, sh);
-        else
-            ntt_round<1>(data, tw, tile, ntw, lp, g, sh);
+        const bool last = (sh - R + 1 == 0);
+        if (R == 3) {
+            if (last) ntt_round<3, true>(data, tw, tile, ntw, lp, g, sh);
+            else ntt_round<3, false>(data, tw, tile, ntw, lp, g, sh);
+        } else if (R == 2) {
+            if (last) ntt_round<2, true>(data, tw, tile, ntw, lp, g, sh);
+            else ntt_round<2, false>(data, tw, tile, ntw, lp, g, sh);
+        } else {
+            ntt_round<1, true>(data, tw, tile, ntw, lp, g, sh);  // a single stage is only ever the last one
+        }
         sh -= R;
         __syncthreads();
     }
