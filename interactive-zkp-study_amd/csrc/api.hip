@@ -73,6 +73,52 @@ __global__ __launch_bounds__(64) void group_op_kernel(int op, const uint32_t *p,
     store_affine_canonical(out + (size_t)i * PW, xyzz_to_affine(r));
 }
 
+// Fixed-base batch k_i * P (setup side: powers of tau / x in the exponent):
+// a table T[j][d-1] = d * 2^(8j) * P (32 byte-windows x 255 digits, affine) is built once per call, then
+// every scalar costs at most 32 mixed additions and no doubling (the double-and-add it replaces: 256 + ~128).
+constexpr int FB_WINDOWS = 32, FB_DIGITS = 255;
+template <class F>
+__global__ __launch_bounds__(64) void fixed_base_table_kernel(const uint32_t *base, Affine<F> *table) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= FB_WINDOWS * FB_DIGITS) return;
+    const uint32_t j = i / FB_DIGITS, d = i % FB_DIGITS + 1;
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    k[j >> 2] = d << (8 * (j & 3));
+    table[i] = xyzz_to_affine(xyzz_scalar_mul(load_affine_canonical<F>(base), k));
+}
+template <class F>
+__global__ __launch_bounds__(64) void fixed_base_eval_kernel(const Affine<F> *__restrict__ table, const uint32_t *__restrict__ scalars,
+                                                             uint32_t *__restrict__ out, uint32_t n) {
+    constexpr int PW = 2 * F::CANON_WORDS;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[8];
+    for (int j = 0; j < 8; j++) k[j] = scalars[(size_t)i * 8 + j];
+    Xyzz<F> acc = Xyzz<F>::inf();
+#pragma unroll 1
+    for (int j = 0; j < FB_WINDOWS; j++) {
+        const uint32_t d = (k[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        if (d) xyzz_add_affine(acc, table[j * FB_DIGITS + d - 1]);
+    }
+    store_affine_canonical(out + (size_t)i * PW, xyzz_to_affine(acc));
+}
+
+template <class F> static int group_op_host(int op, const uint64_t *p, const uint64_t *q, size_t n, uint64_t *out);
+template <class F> static int fixed_base_host(const uint64_t *base, const uint64_t *scalars, size_t n, uint64_t *out) {
+    constexpr size_t PB = 8 * F::CANON_WORDS;
+    if (n == 0) return ZK_OK;
+    if (n < 4096) return group_op_host<F>(2, base, scalars, n, out);  // the table alone is 8160 scalar multiplications
+    DevBuf dbase(PB), table((size_t)FB_WINDOWS * FB_DIGITS * sizeof(Affine<F>)), dk(n * 32), dout(n * PB);
+    ZK_HIP(hipMemcpy(dbase.p, base, PB, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(dk.p, scalars, n * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((fixed_base_table_kernel<F>), dim3((FB_WINDOWS * FB_DIGITS + 63) / 64), dim3(64), 0, 0, dbase.as<uint32_t>(), table.as<Affine<F>>());
+    hipLaunchKernelGGL((fixed_base_eval_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, table.as<Affine<F>>(), dk.as<uint32_t>(),
+                       dout.as<uint32_t>(), (uint32_t)n);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpy(out, dout.p, n * PB, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+
 // Arithmetic-rate probes (zk_measure_rate): the integer-ALU ceilings the MSM kernels are priced against.
 // Every thread runs a dependent chain, the grid oversubscribes the chip, so the rate is the chip-wide
 // issue limit of the field multiplication / the mixed addition as compiled into this library.
@@ -319,7 +365,7 @@ int zk_fixed_base_g1(const uint64_t base_xy[8], const uint64_t *scalars, size_t 
         if (!base_xy || (n && (!scalars || !out_points))) return invalid("zk_fixed_base_g1: null pointer");
         int rc = require_device();
         if (rc) return rc;
-        return group_op_host<Fp>(2, base_xy, scalars, n, out_points);
+        return fixed_base_host<Fp>(base_xy, scalars, n, out_points);
     });
 }
 int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t n, uint64_t *out_points) {
@@ -327,7 +373,7 @@ int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t
         if (!base_xy || (n && (!scalars || !out_points))) return invalid("zk_fixed_base_g2: null pointer");
         int rc = require_device();
         if (rc) return rc;
-        return group_op_host<Fp2>(2, base_xy, scalars, n, out_points);
+        return fixed_base_host<Fp2>(base_xy, scalars, n, out_points);
     });
 }
 int zk_measure_rate(int what, double *out_per_sec) {

@@ -247,3 +247,31 @@ def test_g1_msm_2pow20_closed_form_and_linearity():
     dbl = co.to_limbs([2 * v % o.R for v in co.from_limbs(S[:4096])])
     d = msm_g1(dbl, np.ascontiguousarray(Pts[:4096]))
     assert co.g1_from_arr(d)[0] == co.g1_add(co.g1_from_arr(a)[0], co.g1_from_arr(a)[0])
+
+
+@pytest.mark.parametrize("n", [5, 4096, 5000])
+def test_fixed_base_batches_bit_exact(n):
+    """zk_fixed_base_g1/g2 (setup.py:18-69, srs.py:77-85): below 4096 scalars one double-and-add per thread, from
+    4096 on the byte-window table kernel -- both against the oracle's k*P, with edge scalars and a non-generator base."""
+    rng = np.random.default_rng(900 + n)
+    K = rand_fr_limbs(rng, n)
+    K[0], K[1], K[2] = 0, limb_row(1), limb_row(o.R - 1)
+    K[3] = limb_row(255 << 248 >> 2)            # only the top byte-window set
+    K[4] = limb_row((1 << 256) - 1)             # not reduced mod r: the kernel takes all 256 bits, like bn128.multiply
+    lib = _lib.load()
+    base1 = co.g1_to_arr([co.g1_mul(o.G1, 7)])
+    out1 = np.zeros((n, 8), dtype=np.uint64)
+    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(base1), _lib.ptr(K), n, _lib.ptr(out1)))
+    idx = list(range(8)) + [n // 2, n - 1] if n > 8 else list(range(n))
+    assert np.array_equal(out1[idx], co.g1_fixed_base_arr(co.g1_from_arr(base1)[0], K[idx]))
+    base2 = co.g2_to_arr([o.G2])
+    out2 = np.zeros((n, 16), dtype=np.uint64)
+    _lib.check(lib.zk_fixed_base_g2(_lib.ptr(base2), _lib.ptr(K), n, _lib.ptr(out2)))
+    for i in idx[:6] + idx[-1:]:
+        want = np.zeros(16, dtype=np.uint64)
+        co.lib().orc_g2_mul(co._p(base2), co._p(K[i:i + 1].copy()), co._p(want))
+        assert np.array_equal(out2[i], want), i
+    # infinity base -> all results infinity (zeros)
+    zero = np.zeros((1, 8), dtype=np.uint64)
+    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(zero), _lib.ptr(K), n, _lib.ptr(out1)))
+    assert not out1.any()
