@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 size of the secondary NTT measurement (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="points timed on the pure-Python baseline (0 = skip)")
     ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +92,10 @@ def main():
     lib = _lib.load()
     _lib.check(lib.zk_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
     n = 1 << args.log_n
 
@@ -113,7 +117,7 @@ def main():
     # overlaps the GPU work of step k+1, as it does in a prover issuing its MSMs back to back.  Every
     # step's pipeline, read-back, fold (and for N > 1 its all-gather) completes inside the timed region.
     def finish(ticket):
-        if world == 1:
+        if not dist_on:
             return plan.collect_limbs(ticket)
         return sharded_msm(_lib.GROUP_G1, plan.collect_partial(ticket), device=dev)
 
@@ -132,7 +136,7 @@ def main():
         return res
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +148,7 @@ def main():
     result = run_steps(args.steps, stage)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -152,7 +156,7 @@ def main():
 
     # ---- correctness of the timed result: closed form (sum_i s_i k_i mod r) * G1
     local_dot = limbs_dot_mod_r(scalars, ks)
-    if world > 1:
+    if dist_on:
         dots = [None] * world
         dist.all_gather_object(dots, local_dot)
         total_dot = sum(dots) % R_MOD
@@ -292,7 +296,7 @@ def main():
             "extra": extra,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if not verified:

@@ -22,17 +22,40 @@ def shard_range(n, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_gather_ctx = {}
+
+
 def all_gather_partials(partial, device=None, group=None):
-    """partial: uint64[L] on the host -> uint64[world, L] (rank order) on every rank."""
+    """partial: uint64[L] on the host -> uint64[world, L] (rank order) on every rank.
+
+    On a GPU the copy-in, the collective and the copy-out run on a side stream of their own, so they wait
+    for nothing the caller has queued on its compute stream since (bench.py keeps the next MSM in flight
+    while the previous step's partials are exchanged); buffers are allocated once per (device, size)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    t = torch.from_numpy(np.ascontiguousarray(partial).view(np.int64).copy())
-    if device is not None:
-        t = t.to(device)
-    out = torch.empty(world * t.numel(), dtype=torch.int64, device=t.device)  # flat: gloo and RCCL both accept it
-    dist.all_gather_into_tensor(out, t, group=group)
-    return out.cpu().numpy().view(np.uint64).reshape(world, -1)
+    src = np.ascontiguousarray(partial).view(np.int64)
+    if device is None or torch.device(device).type != "cuda":
+        t = torch.from_numpy(src.copy())
+        out = torch.empty(world * t.numel(), dtype=torch.int64)  # flat: gloo and RCCL both accept it
+        dist.all_gather_into_tensor(out, t, group=group)
+        return out.numpy().view(np.uint64).reshape(world, -1)
+    key = (str(device), src.size, world)
+    ctx = _gather_ctx.get(key)
+    if ctx is None:
+        ctx = {"stream": torch.cuda.Stream(device=device, priority=-1),  # ahead of the bulk MSM kernels
+               "h_in": torch.empty(src.size, dtype=torch.int64).pin_memory(),
+               "d_in": torch.empty(src.size, dtype=torch.int64, device=device),
+               "d_out": torch.empty(world * src.size, dtype=torch.int64, device=device),
+               "h_out": torch.empty(world * src.size, dtype=torch.int64).pin_memory()}
+        _gather_ctx[key] = ctx
+    ctx["h_in"].numpy()[:] = src
+    with torch.cuda.stream(ctx["stream"]):
+        ctx["d_in"].copy_(ctx["h_in"], non_blocking=True)
+        dist.all_gather_into_tensor(ctx["d_out"], ctx["d_in"], group=group)
+        ctx["h_out"].copy_(ctx["d_out"], non_blocking=True)
+    ctx["stream"].synchronize()
+    return ctx["h_out"].numpy().view(np.uint64).reshape(world, -1).copy()
 
 
 def fold_partials(group_id, partials):
