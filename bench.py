@@ -67,8 +67,8 @@ def limbs_dot_mod_r(a, b):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of points per GPU")
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 size of the secondary NTT measurement (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="points timed on the pure-Python baseline (0 = skip)")
@@ -113,26 +113,30 @@ def main():
     plan = MsmPlan(_lib.GROUP_G1, n)
     plan.set_profiling(True)
 
-    # Steps are pipelined two deep (zk_msm_submit / zk_msm_collect): the ~0.2 ms host fold of step k
-    # overlaps the GPU work of step k+1, as it does in a prover issuing its MSMs back to back.  Every
-    # step's pipeline, read-back, fold (and for N > 1 its all-gather) completes inside the timed region.
+    # Steps are pipelined (zk_msm_submit / zk_msm_collect, plan.max_in_flight() = 3 outstanding): every
+    # submission runs in its own workspace and stream, so consecutive MSMs overlap on the GPU and the
+    # ~0.2 ms host fold of step k hides behind the following steps, as in a prover issuing its MSMs back to
+    # back.  Every step's pipeline, read-back, fold (and for N > 1 its all-gather) completes inside the
+    # timed region.
     def finish(ticket):
         if not dist_on:
             return plan.collect_limbs(ticket)
         return sharded_msm(_lib.GROUP_G1, plan.collect_partial(ticket), device=dev)
 
+    depth = plan.max_in_flight()
+
     def run_steps(k, stage_acc=None):
-        res = None
-        pending = plan.submit(d_scalars.data_ptr(), d_points.data_ptr(), n, stream)
-        for _ in range(k - 1):
-            nxt = plan.submit(d_scalars.data_ptr(), d_points.data_ptr(), n, stream)
-            res = finish(pending)
+        res, pending = None, []
+        for _ in range(k):
+            pending.append(plan.submit(d_scalars.data_ptr(), d_points.data_ptr(), n, stream))
+            if len(pending) == depth:
+                res = finish(pending.pop(0))
+                if stage_acc is not None:
+                    stage_acc += np.array(plan.stage_ms())
+        while pending:
+            res = finish(pending.pop(0))
             if stage_acc is not None:
                 stage_acc += np.array(plan.stage_ms())
-            pending = nxt
-        res = finish(pending)
-        if stage_acc is not None:
-            stage_acc += np.array(plan.stage_ms())
         return res
 
     def fence():

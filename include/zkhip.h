@@ -71,8 +71,11 @@ int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n);
  * {prepare, bucket sort, bucket accumulation, bucket reduction}. */
 int zk_msm_plan_profile(zk_msm_plan *plan, int enable);
 int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[4]);
-/* Runs the whole MSM on `stream`; returns after the (tiny) window sums have been read back
- * and folded, i.e. the result is final.  out_xy: 8 (G1) or 16 (G2) limbs on the HOST. */
+/* Runs the whole MSM; returns after the (tiny) window sums have been read back and folded, i.e. the
+ * result is final.  out_xy: 8 (G1) or 16 (G2) limbs on the HOST.  Stream semantics (all device calls
+ * of a plan): the kernels run on a stream owned by the plan; they start after everything queued on
+ * `stream` so far, and `stream` continues once the first kernel has consumed d_scalars / d_points,
+ * so the caller may overwrite its inputs in stream order as usual. */
 int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n,
                uint64_t *out_xy, int *out_is_inf, void *stream);
 /* Same, but returns the result as a projective partial sum (HOST, 16 limbs per coordinate set:
@@ -80,9 +83,12 @@ int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, s
 int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n,
                        uint64_t *out_xyzz, void *stream);
 /* Pipelined form of the two calls above: zk_msm_submit enqueues the whole GPU pipeline (and the
- * 36 KiB read-back) on `stream` and returns at once with a ticket; zk_msm_collect / _collect_partial
- * wait for that submission and do the host fold.  Up to TWO submissions may be in flight per plan, so
- * the host fold of MSM k overlaps the GPU work of MSM k+1 (a prover issues 5-17 MSMs back to back). */
+ * 36 KiB read-back) and returns at once with a ticket; zk_msm_collect / _collect_partial wait for
+ * that submission and do the host fold.  Up to zk_msm_plan_max_in_flight(plan) submissions (3 for
+ * plans of <= 2^22 points, else 2) may be outstanding; each runs in its own workspace and stream, so
+ * consecutive MSMs overlap on the GPU and the host fold of MSM k hides behind MSM k+1 (a prover
+ * issues 5-17 MSMs back to back).  Tickets are collected in any order. */
+int zk_msm_plan_max_in_flight(const zk_msm_plan *plan);
 int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket);
 int zk_msm_collect(zk_msm_plan *plan, int ticket, uint64_t *out_xy, int *out_is_inf);
 int zk_msm_collect_partial(zk_msm_plan *plan, int ticket, uint64_t *out_xyzz);

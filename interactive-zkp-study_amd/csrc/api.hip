@@ -319,6 +319,7 @@ int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[4]) {
     return ZK_OK;
 }
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n) { return plan ? plan->impl->window_bits(n) : ZK_ERR_INVALID; }
+int zk_msm_plan_max_in_flight(const zk_msm_plan *plan) { return plan ? plan->impl->max_in_flight() : ZK_ERR_INVALID; }
 int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, void *stream) {
     return guarded([&] {
         if (!plan || !out_xy || (n && (!d_scalars || !d_points))) return invalid("zk_msm_dev: null pointer");

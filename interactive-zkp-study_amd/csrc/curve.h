@@ -42,7 +42,7 @@ template <class F> ZK_HD Xyzz<F> xyzz_dbl_affine(const Affine<F> &p) {
     F m = fe_triple(fe_sqr(p.x));            // < 6m
     Xyzz<F> r;
     r.x = fe_sub<4>(fe_sqr(m), fe_dbl(s));   // < 6m
-    r.y = fe_sub<2>(fe_mul(m, fe_sub<6>(s, r.x)), fe_mul(w, p.y));  // < 4m
+    r.y = fe_mulsub<2>(m, fe_sub<6>(s, r.x), p.y, w);  // 6*8 + 2*2 < 169;  < 2m
     r.zz = v;
     r.zzz = w;
     return r;
@@ -58,7 +58,7 @@ template <class F> ZK_HD Xyzz<F> xyzz_dbl(const Xyzz<F> &p) {
     F m = fe_triple(fe_sqr(p.x));            // < 6m
     Xyzz<F> r;
     r.x = fe_sub<4>(fe_sqr(m), fe_dbl(s));   // < 6m
-    r.y = fe_sub<2>(fe_mul(m, fe_sub<6>(s, r.x)), fe_mul(w, p.y));  // < 4m
+    r.y = fe_mulsub<4>(m, fe_sub<6>(s, r.x), p.y, w);  // 6*8 + 4*2 < 169;  < 2m
     r.zz = fe_mul(v, p.zz);
     r.zzz = fe_mul(w, p.zzz);
     return r;
@@ -86,7 +86,7 @@ template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) 
     F ppp = fe_mul(p, pp);
     F qq = fe_mul(acc.x, pp);                // 8*2
     F x3 = fe_sub<6>(fe_sqr(r), fe_add(ppp, fe_dbl(qq)));           // < 8m
-    F y3 = fe_sub<2>(fe_mul(r, fe_sub<8>(qq, x3)), fe_mul(acc.y, ppp));  // 6*10 < 169;  < 4m
+    F y3 = fe_mulsub<4>(r, fe_sub<8>(qq, x3), acc.y, ppp);           // 6*10 + 4*2 < 169;  < 2m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(acc.zz, pp);
@@ -117,7 +117,7 @@ template <class F> ZK_HD void xyzz_add(Xyzz<F> &acc, const Xyzz<F> &q) {
     F ppp = fe_mul(p, pp);
     F qq = fe_mul(u1, pp);
     F x3 = fe_sub<6>(fe_sqr(r), fe_add(ppp, fe_dbl(qq)));           // < 8m
-    F y3 = fe_sub<2>(fe_mul(r, fe_sub<8>(qq, x3)), fe_mul(s1, ppp));     // 4*10;  < 4m
+    F y3 = fe_mulsub<2>(r, fe_sub<8>(qq, x3), s1, ppp);              // 4*10 + 2*2 < 169;  < 2m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);

@@ -281,6 +281,59 @@ template <class Tag> ZK_HD Fe<Tag> fe_mul(const Fe<Tag> &a, const Fe<Tag> &b) {
     return r;
 }
 
+// sum_t a[t] * b[t] with ONE Montgomery reduction: the N products are accumulated column-wise before the
+// reduction runs, saving (N-1) * (81 + 9) multiply-adds over N separate fe_mul.  Operands must be normalised
+// (limbs < 2^29: N * 9 + 10 columns-units < 64) and sum_t va[t] * vb[t] < 169;  result < 2m.
+template <int N, class Tag> ZK_HD Fe<Tag> fe_dot(const Fe<Tag> *const (&a)[N], const Fe<Tag> *const (&b)[N]) {
+    typedef FieldConst<Tag> C;
+    static_assert(N * 9 + 10 < 64, "fe_dot: column accumulator would overflow");
+    uint32_t q[NL];
+    Fe<Tag> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (uint64_t)a[t]->l[i] * b[t]->l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        q[k] = ((uint32_t)acc * C::inv) & LMASK;
+        acc += (uint64_t)q[k] * C::mod(0);
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+#pragma unroll
+            for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a[t]->l[i] * b[t]->l[k - i];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        r.l[k - NL] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    r.l[NL - 1] = (uint32_t)acc;
+#ifdef ZK_FIELD_DEBUG
+    double vsum = 0;
+    for (int t = 0; t < N; t++) {
+        vsum += a[t]->vb * b[t]->vb;
+        ZK_DBG_ASSERT(a[t]->lmax <= 1 && b[t]->lmax <= 1, "fe_dot: operands must be normalised");
+    }
+    ZK_DBG_ASSERT(vsum < 169.0, "fe_dot: sum of value bounds >= 169");
+    r.vb = vsum / 169.0 + 1.0;
+    r.lmax = 1;
+#endif
+    return r;
+}
+// a*b - c*d (c <= K*m), one reduction;  result < 2m.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_mulsub(const Fe<Tag> &a, const Fe<Tag> &b, const Fe<Tag> &c, const Fe<Tag> &d) {
+    const Fe<Tag> nc = fe_neg_k<K>(c);
+    const Fe<Tag> *const x[2] = {&a, &nc};
+    const Fe<Tag> *const y[2] = {&b, &d};
+    return fe_dot<2>(x, y);
+}
+
 // Montgomery square: 45 distinct products instead of 81.
 template <class Tag> ZK_HD Fe<Tag> fe_sqr(const Fe<Tag> &a) {
     typedef FieldConst<Tag> C;
@@ -429,15 +482,24 @@ ZK_HD Fp2 fe_triple(const Fp2 &a) {
     fe_wreduce<8>(r.c1);
     return r;
 }
-// Karatsuba: 3 base-field products.
+// Schoolbook with lazy reduction: c0 = a0 b0 + a1 (-b1), c1 = a0 b1 + a1 b0 -- four limb products but only two
+// Montgomery reductions (fe_dot<2>), cheaper here than Karatsuba's three full multiplications plus its
+// additions.  Components < 2p in, < 2p out (sum of value bounds 8 < 169).
 ZK_HD Fp2 fe_mul(const Fp2 &a, const Fp2 &b) {
-    const Fp v0 = fe_mul(a.c0, b.c0);
-    const Fp v1 = fe_mul(a.c1, b.c1);
-    const Fp s = fe_mul(fe_add_lazy(a.c0, a.c1), fe_add_lazy(b.c0, b.c1));
-    Fp2 r{fe_sub_k<2>(v0, v1), fe_sub_k<4>(s, fe_add(v0, v1))};
-    fe_wreduce<4>(r.c0);
-    fe_wreduce<8>(r.c1);
-    return r;
+    const Fp nb1 = fe_neg_k<2>(b.c1);
+    const Fp *const x[2] = {&a.c0, &a.c1};
+    const Fp *const y0[2] = {&b.c0, &nb1};
+    const Fp *const y1[2] = {&b.c1, &b.c0};
+    return Fp2{fe_dot<2>(x, y0), fe_dot<2>(x, y1)};
+}
+// a*b - c*d in F_p^2 with two reductions (fe_dot<4> per component).  K is ignored: components are < 2p.
+template <int K> ZK_HD Fp2 fe_mulsub(const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
+    const Fp nb1 = fe_neg_k<2>(b.c1), nc0 = fe_neg_k<2>(c.c0), nc1 = fe_neg_k<2>(c.c1);
+    const Fp *const x0[4] = {&a.c0, &a.c1, &nc0, &c.c1};
+    const Fp *const y0[4] = {&b.c0, &nb1, &d.c0, &d.c1};
+    const Fp *const x1[4] = {&a.c0, &a.c1, &nc0, &nc1};
+    const Fp *const y1[4] = {&b.c1, &b.c0, &d.c1, &d.c0};
+    return Fp2{fe_dot<4>(x0, y0), fe_dot<4>(x1, y1)};
 }
 // (c0+c1 i)^2 = (c0+c1)(c0-c1) + 2 c0 c1 i : 2 base-field products.
 ZK_HD Fp2 fe_sqr(const Fp2 &a) {

@@ -147,6 +147,9 @@ template <class Tag> inline HFe<Tag> fe_mul(const HFe<Tag> &a, const HFe<Tag> &b
     return r;
 }
 template <class Tag> inline HFe<Tag> fe_sqr(const HFe<Tag> &a) { return fe_mul(a, a); }
+template <int K, class Tag> inline HFe<Tag> fe_mulsub(const HFe<Tag> &a, const HFe<Tag> &b, const HFe<Tag> &c, const HFe<Tag> &d) {
+    return fe_sub(fe_mul(a, b), fe_mul(c, d));
+}
 template <class Tag> inline HFe<Tag> fe_pow(const HFe<Tag> &a, const uint64_t e[4]) {
     HFe<Tag> r = HFe<Tag>::one();
     for (int i = 3; i >= 0; i--)
@@ -194,6 +197,7 @@ inline HFp2 fe_sqr(const HFp2 &a) {
     HFp u = fe_mul(fe_add(a.c0, a.c1), fe_sub(a.c0, a.c1));
     return HFp2{u, fe_dbl(t)};
 }
+template <int K> inline HFp2 fe_mulsub(const HFp2 &a, const HFp2 &b, const HFp2 &c, const HFp2 &d) { return fe_sub(fe_mul(a, b), fe_mul(c, d)); }
 inline HFp2 fe_inv(const HFp2 &a) {
     HFp d = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
     return HFp2{fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};

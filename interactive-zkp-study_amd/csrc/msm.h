@@ -13,9 +13,10 @@ struct MsmPlanBase {
     float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};  // last run: prepare, bucket sort, accumulate, reduce (device ms)
     virtual ~MsmPlanBase() {}
     virtual int window_bits(size_t n) const = 0;
+    virtual int max_in_flight() const = 0;  // submissions that may be outstanding before one must be collected
     virtual int run_affine(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, hipStream_t st) = 0;
     virtual int run_partial(const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, hipStream_t st) = 0;
-    // pipelined form: up to two submissions in flight per plan
+    // pipelined form: up to max_in_flight() submissions outstanding per plan
     virtual int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) = 0;
     virtual int collect_affine(int ticket, uint64_t *out_xy, int *out_is_inf) = 0;
     virtual int collect_partial(int ticket, uint64_t *out_xyzz) = 0;

@@ -17,7 +17,6 @@
 //   fold (host)  the W*(c) window/level sums (32 KiB) are read back and combined by one
 //                254-doubling Horner pass on the host (a single GPU thread would be latency-bound).
 #pragma once
-#include <vector>
 #include "common.h"
 #include "curve.h"
 #include "host_field.h"
@@ -469,27 +468,28 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbu
 // One thread per bucket, one wavefront per workgroup, buckets taken in order of decreasing list
 // length (perm[]): the 64 lanes of a wavefront own lists of (nearly) equal length, wavefronts retire
 // independently and the longest lists start first.  Each thread adds its points in XYZZ mixed
-// coordinates (8M+2S per point), the next (index, point) pair being fetched under the current add.
-// Sum of the points listed in lst[0..len): XYZZ mixed additions with the next entry prefetched.
+// coordinates (8M+2S per point), the next point and the index after it being fetched under the current add.
 template <class F>
 __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ lst, uint32_t len) {
     Xyzz<F> acc = Xyzz<F>::inf();
-    if (len) {
-        uint32_t e = lst[0];
-        PackedAffine<F> pk = pts[e & 0x7fffffffu];
-        for (uint32_t k = 1; k <= len; k++) {
-            uint32_t e2 = 0;
-            PackedAffine<F> pk2 = pk;
-            if (k < len) {
-                e2 = lst[k];
-                pk2 = pts[e2 & 0x7fffffffu];
-            }
-            Affine<F> p = unpack_affine(pk);
-            if (e >> 31) p.y = fe_neg<2>(p.y);
-            xyzz_add_affine(acc, p);
-            e = e2;
-            pk = pk2;
-        }
+    if (len == 0) return acc;
+    // Two-deep software pipeline, branch-free loads (indices clamp to the last entry): at the top of every
+    // iteration the loads of the NEXT point (its index arrived an iteration ago) and of the index after it are
+    // issued, then the current point is added -- no load is ever waited for in the iteration that issued it.
+    const uint32_t last = len - 1;
+    uint32_t e = lst[0];
+    uint32_t e_n = lst[min(1u, last)];
+    PackedAffine<F> pk = pts[e & 0x7fffffffu];
+#pragma unroll 1
+    for (uint32_t k = 0; k < len; k++) {
+        const PackedAffine<F> pk_n = pts[e_n & 0x7fffffffu];
+        const uint32_t e_nn = lst[min(k + 2, last)];
+        Affine<F> p = unpack_affine(pk);
+        if (e >> 31) p.y = fe_neg<2>(p.y);
+        xyzz_add_affine(acc, p);
+        e = e_n;
+        e_n = e_nn;
+        pk = pk_n;
     }
     return acc;
 }
@@ -670,191 +670,213 @@ static int pick_window_bits(size_t n) {
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
-    DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, zcount, size_bins, perm, arena, out, heavy_tasks, heavy_buckets, heavy_partial;
+    size_t dig_bytes = 0, arena_bytes = 0, out_bytes_max = 0;
     uint32_t heavy_cap = 0;
-    // heavy buckets are summed on a second stream, beside the main accumulate kernel
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // Two submissions may be in flight: the 36 KiB read-back buffer, its completion event and the
-    // profiling events are per slot, everything else is reused in stream order.
-    static constexpr int SLOTS = 2;
-    struct Slot {
-        PinnedBuf h_out;
-        hipEvent_t done = nullptr;
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
-        bool busy = false, empty = false, profiled = false;
-        int c = 0;
-    } slots[SLOTS];
-    int next_slot = 0, cur = 0;
 
-    static constexpr int MAXC = 16;
+    // A lane is everything one in-flight MSM owns: its workspace, a stream of its own (plus the side stream
+    // of the heavy-bucket kernels) and the read-back buffer.  Submissions rotate through the lanes, so the
+    // kernels of consecutive MSMs overlap on the GPU: the sort and reduce phases and the accumulate kernel's
+    // tail leave CUs idle that the neighbouring MSM's accumulate kernel fills (2^20 points: 1.89 -> 1.73 ms per
+    // MSM with three lanes).  Lanes beyond the first are allocated on first use.
+    struct Lane {
+        DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, zcount, size_bins, perm, arena, out, heavy_tasks, heavy_buckets,
+            heavy_partial;
+        PinnedBuf h_out;
+        hipStream_t stream = nullptr, aux = nullptr;
+        hipEvent_t ev_in = nullptr, ev_consumed = nullptr, ev_fork = nullptr, ev_join = nullptr, done = nullptr;
+        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
+        bool ready = false, busy = false, empty = false, profiled = false;
+        int c = 0;
+    };
+    static constexpr int MAX_LANES = 3;
+    Lane lanes[MAX_LANES];
+    int nlanes = 1, next_lane = 0;
+
     explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
         group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
-        size_t n_pad = pad_n(max_n);
-        pts_m.alloc(max_n * sizeof(PackedAffine<F>));
-        // digits: worst case over the window choices available to n <= max_n
-        size_t dig = 0, ar = 0, outn = 0;
+        const size_t n_pad = pad_n(max_n);
+        // worst case over the window choices available to n <= max_n
         const int cs[5] = {8, 10, 13, 15, 16};
         for (int c : cs) {
             if (c > pick_window_bits(max_n)) continue;
             size_t W = (255 + c - 1) / c, nb = (size_t)1 << (c - 1);
-            dig = std::max(dig, W * n_pad * sizeof(int16_t));
-            ar = std::max(ar, W * nb * sizeof(Xyzz<F>));
-            outn = std::max(outn, W * (size_t)c * sizeof(Xyzz<F>));
+            dig_bytes = std::max(dig_bytes, W * n_pad * sizeof(int16_t));
+            arena_bytes = std::max(arena_bytes, W * nb * sizeof(Xyzz<F>));
+            out_bytes_max = std::max(out_bytes_max, W * (size_t)c * sizeof(Xyzz<F>));
         }
-        digits.alloc(dig);
-        const size_t span_slack = (size_t)MAX_CELLS * 16 + 64;  // cell spans are padded to 16 entries
-        sorted.alloc(dig * 2 + span_slack * 4);  // one 4-byte entry per (window, point)
-        counts.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
-        bucket_off.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
-        e_idx.alloc(dig * 2 + span_slack * 4);
-        e_loc.alloc(dig / 2 + span_slack);
-        cells.alloc(4 * MAX_CELLS * sizeof(uint32_t));  // cell_total | cell_base | cell_cnt | cell_cursor
-        ZK_HIP(hipMemset(cells.p, 0, 4 * MAX_CELLS * sizeof(uint32_t)));
-        size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
-        ZK_HIP(hipMemset(size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
-        zcount.alloc((size_t)MAX_CELLS * SEG_Z * SEG_BUCKETS * sizeof(uint32_t));
         // heavy-bucket scratch: a heavy bucket holds > heavy_th >= HEAVY_SEG entries, so there are < entries / HEAVY_SEG of
         // them and sum ceil(len / HEAVY_WAVE) <= entries / HEAVY_WAVE + (heavy buckets) wavefront tasks; entries <= W * n_pad
-        heavy_cap = (uint32_t)(dig / sizeof(int16_t) / HEAVY_SEG + dig / sizeof(int16_t) / HEAVY_WAVE + 64);
-        ZK_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        ZK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        ZK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        heavy_tasks.alloc((size_t)heavy_cap * sizeof(uint2));
-        heavy_buckets.alloc((size_t)heavy_cap * sizeof(uint4));
-        heavy_partial.alloc((size_t)heavy_cap * sizeof(Xyzz<F>));
-        perm.alloc(ar / sizeof(Xyzz<F>) * sizeof(uint32_t));
-        arena.alloc(ar);
-        out.alloc(outn);
-        for (auto &sl : slots) sl.h_out.alloc(outn);
+        heavy_cap = (uint32_t)(dig_bytes / sizeof(int16_t) / HEAVY_SEG + dig_bytes / sizeof(int16_t) / HEAVY_WAVE + 64);
+        // beyond 2^22 points a single MSM fills the chip for tens of ms and the workspace runs to GBs: two lanes
+        nlanes = max_n <= ((size_t)1 << 22) ? 3 : 2;
+        prepare_lane(lanes[0]);
+    }
+    void prepare_lane(Lane &L) {
+        if (L.ready) return;
+        const size_t dig = dig_bytes, nbk = arena_bytes / sizeof(Xyzz<F>);
+        L.pts_m.alloc(max_n * sizeof(PackedAffine<F>));
+        L.digits.alloc(dig);
+        const size_t span_slack = (size_t)MAX_CELLS * 16 + 64;  // cell spans are padded to 16 entries
+        L.sorted.alloc(dig * 2 + span_slack * 4);               // one 4-byte entry per (window, point)
+        L.counts.alloc(nbk * sizeof(uint32_t));
+        L.bucket_off.alloc(nbk * sizeof(uint32_t));
+        L.e_idx.alloc(dig * 2 + span_slack * 4);
+        L.e_loc.alloc(dig / 2 + span_slack);
+        L.cells.alloc(4 * MAX_CELLS * sizeof(uint32_t));  // cell_total | cell_base | cell_cnt | cell_cursor
+        ZK_HIP(hipMemset(L.cells.p, 0, 4 * MAX_CELLS * sizeof(uint32_t)));
+        L.size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
+        ZK_HIP(hipMemset(L.size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
+        L.zcount.alloc((size_t)MAX_CELLS * SEG_Z * SEG_BUCKETS * sizeof(uint32_t));
+        L.heavy_tasks.alloc((size_t)heavy_cap * sizeof(uint2));
+        L.heavy_buckets.alloc((size_t)heavy_cap * sizeof(uint4));
+        L.heavy_partial.alloc((size_t)heavy_cap * sizeof(Xyzz<F>));
+        L.perm.alloc(nbk * sizeof(uint32_t));
+        L.arena.alloc(arena_bytes);
+        L.out.alloc(out_bytes_max);
+        L.h_out.alloc(out_bytes_max);
+        ZK_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        ZK_HIP(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.ev_fork, &L.ev_join, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        L.ready = true;
     }
     ~MsmPlanImpl() override {
-        if (aux) (void)hipStreamDestroy(aux);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        for (auto &sl : slots) {
-            if (sl.done) (void)hipEventDestroy(sl.done);
-            for (auto &e : sl.ev)
+        for (auto &L : lanes) {
+            if (L.stream) (void)hipStreamSynchronize(L.stream);
+            if (L.aux) (void)hipStreamDestroy(L.aux);
+            if (L.stream) (void)hipStreamDestroy(L.stream);
+            for (hipEvent_t e : {L.ev_in, L.ev_consumed, L.ev_fork, L.ev_join, L.done})
+                if (e) (void)hipEventDestroy(e);
+            for (auto &e : L.ev)
                 if (e) (void)hipEventDestroy(e);
         }
     }
     static size_t pad_n(size_t n) { return ((n + 4095) / 4096) * 4096; }
-    void mark(int i, hipStream_t st) {
-        if (!profile) return;
-        hipEvent_t &e = slots[cur].ev[i];
+    void mark(Lane &L, int i) {
+        if (!L.profiled) return;
+        hipEvent_t &e = L.ev[i];
         if (!e) ZK_HIP(hipEventCreate(&e));
-        ZK_HIP(hipEventRecord(e, st));
+        ZK_HIP(hipEventRecord(e, L.stream));
     }
 
     int window_bits(size_t n) const override { return pick_window_bits(n); }
+    int max_in_flight() const override { return nlanes; }
 
-    template <int C> void launch_prepare(const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad, hipStream_t st) {
-        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, sc, pt,
-                           pts_m.as<PackedAffine<F>>(), digits.as<int16_t>(), cells.as<uint32_t>(), n, n_pad);
+    template <int C> void launch_prepare(Lane &L, const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad) {
+        hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, L.stream, sc, pt,
+                           L.pts_m.template as<PackedAffine<F>>(), L.digits.template as<int16_t>(), L.cells.template as<uint32_t>(), n, n_pad);
     }
-    void launch_sort_accumulate(uint32_t n_pad, uint32_t nb, uint32_t W, hipStream_t st) {
+    void launch_sort_accumulate(Lane &L, uint32_t n_pad, uint32_t nb, uint32_t W) {
+        hipStream_t st = L.stream, aux = L.aux;
         const uint32_t G = (nb + SEG_BUCKETS - 1) / SEG_BUCKETS;
         if (G * W > MAX_CELLS) throw std::runtime_error("zk_msm: too many sort cells");
         SortBufs B;
-        B.counts = counts.as<uint32_t>();
-        B.bucket_off = bucket_off.as<uint32_t>();
-        B.cell_total = cells.as<uint32_t>();
+        B.counts = L.counts.template as<uint32_t>();
+        B.bucket_off = L.bucket_off.template as<uint32_t>();
+        B.cell_total = L.cells.template as<uint32_t>();
         B.cell_base = B.cell_total + MAX_CELLS;
         B.cell_cnt = B.cell_total + 2 * MAX_CELLS;
         B.cell_cursor = B.cell_total + 3 * MAX_CELLS;
-        B.e_idx = e_idx.as<uint32_t>();
-        B.e_loc = e_loc.as<uint8_t>();
-        B.sorted = sorted.as<uint32_t>();
-        B.zcount = zcount.as<uint32_t>();
-        B.size_hist = size_bins.as<uint32_t>();
+        B.e_idx = L.e_idx.template as<uint32_t>();
+        B.e_loc = L.e_loc.template as<uint8_t>();
+        B.sorted = L.sorted.template as<uint32_t>();
+        B.zcount = L.zcount.template as<uint32_t>();
+        B.size_hist = L.size_bins.template as<uint32_t>();
         B.size_base = B.size_hist + SIZE_BINS;
         B.size_cursor = B.size_hist + 2 * SIZE_BINS;
-        B.perm = perm.as<uint32_t>();
+        B.perm = L.perm.template as<uint32_t>();
         B.heavy_th = std::max<uint32_t>(32, 8 * (n_pad / nb));
         B.heavy_cap = heavy_cap;
         B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
-        B.heavy_tasks = heavy_tasks.as<uint2>();
-        B.heavy_buckets = heavy_buckets.as<uint4>();
+        B.heavy_tasks = L.heavy_tasks.template as<uint2>();
+        B.heavy_buckets = L.heavy_buckets.template as<uint4>();
         const uint32_t nbuckets_all = W * nb;
         hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, st, B, G * W);
-        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, digits.as<int16_t>(), B, n_pad, W, G);
+        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B, n_pad, W,
+                           G);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B, nb);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((nbuckets_all + 2047) / 2048), dim3(1024), 0, st, B, nbuckets_all);
-        mark(2, st);
+        mark(L, 2);
         // heavy buckets (normally none) on the aux stream: the grids cover the worst case and exit on the device-side counters
-        ZK_HIP(hipEventRecord(ev_fork, st));
-        ZK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+        ZK_HIP(hipEventRecord(L.ev_fork, st));
+        ZK_HIP(hipStreamWaitEvent(aux, L.ev_fork, 0));
         hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, aux, B);
-        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, aux, pts_m.as<PackedAffine<F>>(), B,
-                           heavy_partial.as<Xyzz<F>>());
-        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, aux, B, heavy_partial.as<Xyzz<F>>(), arena.as<Xyzz<F>>());
-        ZK_HIP(hipEventRecord(ev_join, aux));
+        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, aux,
+                           L.pts_m.template as<PackedAffine<F>>(), B, L.heavy_partial.template as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, aux, B, L.heavy_partial.template as<Xyzz<F>>(),
+                           L.arena.template as<Xyzz<F>>());
+        ZK_HIP(hipEventRecord(L.ev_join, aux));
         const uint32_t nbuckets = W * nb;
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, pts_m.as<PackedAffine<F>>(),
-                           sorted.as<uint32_t>(), counts.as<uint32_t>(), bucket_off.as<uint32_t>(), perm.as<uint32_t>(),
-                           arena.as<Xyzz<F>>(), nbuckets, B.heavy_th);
-        ZK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, L.pts_m.template as<PackedAffine<F>>(),
+                           L.sorted.template as<uint32_t>(), L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(),
+                           L.perm.template as<uint32_t>(), L.arena.template as<Xyzz<F>>(), nbuckets, B.heavy_th);
+        ZK_HIP(hipStreamWaitEvent(st, L.ev_join, 0));
     }
 
-    // Enqueues the whole GPU pipeline plus the 36 KiB read-back on `st`; returns a ticket.
+    // Enqueues the whole GPU pipeline plus the 36 KiB read-back; returns a ticket.  The work runs on the lane's own
+    // stream: it starts once everything queued on `st` so far has finished, and `st` resumes as soon as the prepare
+    // kernel has consumed the caller's scalars and points (the only kernel that reads them).
     int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) override {
         if (n > max_n) throw std::runtime_error("zk_msm: n exceeds the plan's max_n");
-        cur = next_slot;
-        Slot &sl = slots[cur];
-        if (sl.busy) throw std::runtime_error("zk_msm: more than two submissions in flight; collect the oldest first");
-        sl.busy = true;
-        sl.empty = (n == 0);
-        sl.profiled = profile;
-        next_slot = (next_slot + 1) % SLOTS;
-        if (n == 0) return cur;
+        const int ticket = next_lane;
+        Lane &L = lanes[ticket];
+        if (L.busy) throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect the oldest first");
+        prepare_lane(L);
+        L.busy = true;
+        L.empty = (n == 0);
+        L.profiled = profile;
+        next_lane = (next_lane + 1) % nlanes;
+        if (n == 0) return ticket;
         const int c = pick_window_bits(n);
-        sl.c = c;
+        L.c = c;
         const uint32_t W = (255 + c - 1) / c, nb = 1u << (c - 1), levels = c - 1;
         const uint32_t n_pad = (uint32_t)pad_n(n);
         const uint32_t *sc = static_cast<const uint32_t *>(d_scalars), *pt = static_cast<const uint32_t *>(d_points);
-        mark(0, st);
+        ZK_HIP(hipEventRecord(L.ev_in, st));
+        ZK_HIP(hipStreamWaitEvent(L.stream, L.ev_in, 0));
+        mark(L, 0);
         switch (c) {
-            case 8: launch_prepare<8>(sc, pt, (uint32_t)n, n_pad, st); break;
-            case 10: launch_prepare<10>(sc, pt, (uint32_t)n, n_pad, st); break;
-            case 13: launch_prepare<13>(sc, pt, (uint32_t)n, n_pad, st); break;
-            case 15: launch_prepare<15>(sc, pt, (uint32_t)n, n_pad, st); break;
-            default: launch_prepare<16>(sc, pt, (uint32_t)n, n_pad, st); break;
+            case 8: launch_prepare<8>(L, sc, pt, (uint32_t)n, n_pad); break;
+            case 10: launch_prepare<10>(L, sc, pt, (uint32_t)n, n_pad); break;
+            case 13: launch_prepare<13>(L, sc, pt, (uint32_t)n, n_pad); break;
+            case 15: launch_prepare<15>(L, sc, pt, (uint32_t)n, n_pad); break;
+            default: launch_prepare<16>(L, sc, pt, (uint32_t)n, n_pad); break;
         }
-        mark(1, st);
-        launch_sort_accumulate(n_pad, nb, W, st);
-        mark(3, st);
+        ZK_HIP(hipEventRecord(L.ev_consumed, L.stream));
+        ZK_HIP(hipStreamWaitEvent(st, L.ev_consumed, 0));
+        mark(L, 1);
+        launch_sort_accumulate(L, n_pad, nb, W);
+        mark(L, 3);
         {
-            Xyzz<F> *ar = arena.as<Xyzz<F>>();
+            Xyzz<F> *ar = L.arena.template as<Xyzz<F>>();
             const uint32_t BL = std::min<uint32_t>(9, levels);
             const uint32_t threads = std::max<uint32_t>(64, 1u << (BL - 1));
-            hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3((W * nb) >> BL), dim3(threads), 0, st, ar, BL);
-            hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, st, ar, out.as<Xyzz<F>>(), nb, BL, levels);
+            hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3((W * nb) >> BL), dim3(threads), 0, L.stream, ar, BL);
+            hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, L.stream, ar, L.out.template as<Xyzz<F>>(), nb, BL, levels);
         }
-        mark(4, st);
+        mark(L, 4);
         const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
-        ZK_HIP(hipMemcpyAsync(sl.h_out.p, out.p, out_bytes, hipMemcpyDeviceToHost, st));
-        if (!sl.done) ZK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        ZK_HIP(hipEventRecord(sl.done, st));
+        ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, out_bytes, hipMemcpyDeviceToHost, L.stream));
+        ZK_HIP(hipEventRecord(L.done, L.stream));
         ZK_HIP(hipGetLastError());
-        return cur;
+        return ticket;
     }
 
     // Waits for a submission and folds its window/level sums on the host.
     Xyzz<HF> collect(int ticket) {
-        if (ticket < 0 || ticket >= SLOTS || !slots[ticket].busy) throw std::runtime_error("zk_msm: bad ticket");
-        Slot &sl = slots[ticket];
-        sl.busy = false;
-        if (sl.empty) return Xyzz<HF>::inf();
-        ZK_HIP(hipEventSynchronize(sl.done));
-        if (sl.profiled) {
-            for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], sl.ev[i], sl.ev[i + 1]));
+        if (ticket < 0 || ticket >= nlanes || !lanes[ticket].busy) throw std::runtime_error("zk_msm: bad ticket");
+        Lane &L = lanes[ticket];
+        L.busy = false;
+        if (L.empty) return Xyzz<HF>::inf();
+        ZK_HIP(hipEventSynchronize(L.done));
+        if (L.profiled) {
+            for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], L.ev[i], L.ev[i + 1]));
         }
-        const int c = sl.c;
+        const int c = L.c;
         const uint32_t W = (255 + c - 1) / c, levels = c - 1;
         // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
-        const Xyzz<F> *h = sl.h_out.template as<Xyzz<F>>();
+        const Xyzz<F> *h = L.h_out.template as<Xyzz<F>>();
         auto conv = [](const Xyzz<F> &p) { return Xyzz<HF>{HF::from_dev(p.x), HF::from_dev(p.y), HF::from_dev(p.zz), HF::from_dev(p.zzz)}; };
         Xyzz<HF> acc = Xyzz<HF>::inf();
         for (int pos = (int)(c * (W - 1) + levels - 1); pos >= 0; pos--) {

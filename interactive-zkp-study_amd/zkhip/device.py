@@ -39,6 +39,10 @@ class MsmPlan:
     def set_profiling(self, enable):
         _lib.check(_lib.load().zk_msm_plan_profile(self._h, 1 if enable else 0))
 
+    def max_in_flight(self):
+        """Submissions that may be outstanding (submit without collect) on this plan."""
+        return _lib.load().zk_msm_plan_max_in_flight(self._h)
+
     def stage_ms(self):
         """Device time of the last run: (prepare, sort, accumulate, reduce) in ms (HIP events on the
         pipeline's stream; needs set_profiling(True))."""
@@ -59,7 +63,8 @@ class MsmPlan:
             return None
         return (limbs_to_g1(out) if self.group == _lib.GROUP_G1 else limbs_to_g2(out))[0]
 
-    # pipelined form: up to two submissions in flight, so the host fold of one MSM overlaps the GPU work of the next
+    # pipelined form: up to max_in_flight() submissions outstanding; consecutive MSMs overlap on the GPU and the host
+    # fold of one hides behind the next
     def submit(self, d_scalars, d_points, n, stream=0):
         t = ctypes.c_int(-1)
         _lib.check(_lib.load().zk_msm_submit(self._h, d_scalars, d_points, n, stream, ctypes.byref(t)))

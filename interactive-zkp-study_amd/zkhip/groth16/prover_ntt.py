@@ -180,10 +180,12 @@ class ScaleProver:
         for d in (ua, ub, d_c):
             self.ntt.run(d.data_ptr(), True, None, st)
         self.ext_b2[:m].copy_(ub)
-        # the three u-dependent MSMs go first; their host folds overlap the H pipeline below
+        # the MSMs that do not need H go first (each plan keeps up to three in flight, every one in its own workspace and
+        # stream): they overlap each other, the H pipeline below and the host folds
         t_a = self.g1.submit(self.ext_a.data_ptr(), crs.d_s12.data_ptr(), m + 3, st)     # alpha + A(x) + r*delta
         t_b2 = self.g2.submit(self.ext_b2.data_ptr(), crs.d_s22.data_ptr(), m + 2, st)   # beta + B(x) + s*delta in G2
         t_b1 = self.g1.submit(self.ext_b1.data_ptr(), crs.d_s12.data_ptr(), m + 3, st)   # beta + B(x) in G1
+        t_l = self.g1.submit(d_w.data_ptr(), crs.d_s14.data_ptr(), W, st)                # placeholders at public wires are infinity
         # H = (A*B - C) / Z on the coset 5*H: 3 coset NTTs + pointwise quotient + 1 coset inverse NTT
         ca.copy_(ua)
         cb.copy_(ub)
@@ -193,9 +195,8 @@ class ScaleProver:
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
         proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                          # proving.py:23-33
-        t_l = self.g1.submit(d_w.data_ptr(), crs.d_s14.data_ptr(), W, st)                # placeholders at public wires are infinity
-        msm_b1 = self._pt(self.g1, self.g1.collect_limbs(t_b1))
         t_h = self.g1.submit(h.data_ptr(), crs.d_s15.data_ptr(), m - 1, st)
+        msm_b1 = self._pt(self.g1, self.g1.collect_limbs(t_b1))
         msm_l = self._pt(self.g1, self.g1.collect_limbs(t_l))
         msm_h = self._pt(self.g1, self.g1.collect_limbs(t_h))
         proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                         # proving.py:35-45

@@ -148,29 +148,45 @@ def test_device_plan_reuse_partials_and_profile():
 
 
 def test_pipelined_submit_collect():
-    """zk_msm_submit / zk_msm_collect: two submissions in flight, results independent of the overlap."""
+    """zk_msm_submit / zk_msm_collect: max_in_flight submissions outstanding (each in its own lane and stream),
+    collected out of order, inputs overwritten in stream order right after submit, results independent of the overlap."""
     import torch
     rng = np.random.default_rng(21)
     n = 30000
-    S1, S2 = rand_fr_limbs(rng, n), rand_fr_limbs(rng, n)
+    S1, S2, S3 = rand_fr_limbs(rng, n), rand_fr_limbs(rng, n), rand_fr_limbs(rng, n)
     Pts, _ = rand_g1_limbs(rng, n)
-    d1, d2 = torch.from_numpy(S1.view(np.int64)).cuda(), torch.from_numpy(S2.view(np.int64)).cuda()
+    d1, d2, d3 = (torch.from_numpy(S.view(np.int64)).cuda() for S in (S1, S2, S3))
     dP = torch.from_numpy(Pts.view(np.int64)).cuda()
     st = torch.cuda.current_stream().cuda_stream
     plan = MsmPlan(_lib.GROUP_G1, n)
+    assert plan.max_in_flight() == 3
     t1 = plan.submit(d1.data_ptr(), dP.data_ptr(), n, st)
+    d1.zero_()                                                     # stream-ordered reuse of an input buffer
     t2 = plan.submit(d2.data_ptr(), dP.data_ptr(), 5000, st)
+    t3 = plan.submit(d3.data_ptr(), dP.data_ptr(), n, st)
     with pytest.raises(_lib.ZkhipError):
-        plan.submit(d1.data_ptr(), dP.data_ptr(), n, st)          # a third one must wait for a collect
+        plan.submit(d2.data_ptr(), dP.data_ptr(), n, st)          # a fourth one must wait for a collect
+    r3, inf3 = plan.collect_limbs(t3)                              # out of order
     r1, inf1 = plan.collect_limbs(t1)
-    t3 = plan.submit(d1.data_ptr(), dP.data_ptr(), 0, st)          # empty MSM through the same path
+    t4 = plan.submit(d2.data_ptr(), dP.data_ptr(), 0, st)          # empty MSM through the same path
     r2, inf2 = plan.collect_limbs(t2)
-    r3, inf3 = plan.collect_limbs(t3)
+    r4, inf4 = plan.collect_limbs(t4)
     assert np.array_equal(r1, co.g1_msm_arr(S1, Pts)) and not inf1
     assert np.array_equal(r2, co.g1_msm_arr(S2[:5000], Pts[:5000])) and not inf2
-    assert inf3 and not r3.any()
+    assert np.array_equal(r3, co.g1_msm_arr(S3, Pts)) and not inf3
+    assert inf4 and not r4.any()
     with pytest.raises(_lib.ZkhipError):
         plan.collect_limbs(t1)                                     # already collected
+    # a long alternation keeps every lane busy; all results must equal the blocking call's
+    want = [co.g1_msm_arr(S, Pts) for S in (S2, S3)]
+    pend = []
+    for i in range(12):
+        pend.append((i % 2, plan.submit((d2, d3)[i % 2].data_ptr(), dP.data_ptr(), n, st)))
+        if len(pend) == plan.max_in_flight():
+            k, t = pend.pop(0)
+            assert np.array_equal(plan.collect_limbs(t)[0], want[k])
+    for k, t in pend:
+        assert np.array_equal(plan.collect_limbs(t)[0], want[k])
 
 
 def test_g1_msm_2pow16_bit_exact():
