@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 size of the secondary NTT measurement (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="points timed on the pure-Python baseline (0 = skip)")
     ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
+    ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
     args = ap.parse_args()
 
@@ -200,7 +201,7 @@ def main():
                         "roundtrip_exact": bool(torch.equal(d, ref))}
 
     # ---- secondary: "witness-like" scalars: half the scalars are 0 or 1, the rest uniform
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_witness_like:
         wrng = np.random.default_rng(0x5EEDB256)
         wl = scalars.copy()
         pick = wrng.random(n)

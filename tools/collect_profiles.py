@@ -9,7 +9,7 @@ counter passes (`--pmc`) separate from the kernel trace, one counter per pass.""
 import argparse, csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0"]
+BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--no-witness-like"]
 
 
 def sh(cmd, log):
@@ -26,7 +26,7 @@ def run(rnd):
     rc = sh(["python3", "bench.py"], os.path.join(out, "bench_line.log"))
     if rc:
         return rc
-    rc = sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "trace"), "--"] + BENCH_QUICK + ["--steps", "10", "--warmup", "2"],
+    rc = sh(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(out, "trace"), "--"] + BENCH_QUICK + ["--steps", "20", "--warmup", "4"],
             os.path.join(out, "trace.log"))
     if rc:
         return rc
@@ -49,14 +49,15 @@ def fold(rnd):
     line = [l for l in open(os.path.join(src, "bench_line.log")) if l.startswith("{")][-1]
     with open(os.path.join(dst, rnd + "_bench_line.json"), "w") as f:
         f.write(line)
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if stats:
-        with open(stats[0]) as f, open(os.path.join(dst, rnd + "_bench_kernel_stats.csv"), "w") as g:
+        with open(stats[-1]) as f, open(os.path.join(dst, rnd + "_bench_kernel_stats.csv"), "w") as g:
             g.write(f.read())
     rows = []
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        for path in glob.glob(os.path.join(src, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True):
+        found = glob.glob(os.path.join(src, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True)
+        for path in sorted(found, key=os.path.getmtime)[-1:]:  # gpurun merges into gpurun_out/: keep the newest pass only
             acc = {}
             for r in csv.DictReader(open(path)):
                 if r.get("Counter_Name") != ctr:
