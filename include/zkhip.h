@@ -67,8 +67,10 @@ int zk_msm_plan_destroy(zk_msm_plan *plan);
 /* Window width the plan will use for n points (Pippenger c); informational. */
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n);
 /* Measurement hooks: with profiling enabled each run records HIP events on the pipeline's own
- * stream around its stages; zk_msm_plan_stage_ms returns the last run's device time in ms for
- * {prepare, bucket sort, bucket accumulation, bucket reduction}. */
+ * stream; zk_msm_plan_stage_ms returns, for the submission collected last, the spans in ms of
+ * {prepare, bucket sort, the bucket-accumulation kernel alone, bucket reduction}.  With several
+ * submissions outstanding the spans other than the accumulation kernel's include time spent waiting
+ * for the GPU. */
 int zk_msm_plan_profile(zk_msm_plan *plan, int enable);
 int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[4]);
 /* Runs the whole MSM; returns after the (tiny) window sums have been read back and folded, i.e. the

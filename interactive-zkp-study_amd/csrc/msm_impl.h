@@ -673,8 +673,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     size_t dig_bytes = 0, arena_bytes = 0, out_bytes_max = 0;
     uint32_t heavy_cap = 0;
 
-    // A lane is everything one in-flight MSM owns: its workspace, a stream of its own (plus the side stream
-    // of the heavy-bucket kernels) and the read-back buffer.  Submissions rotate through the lanes, so the
+    // A lane is everything one in-flight MSM owns: its workspace, a stream of its own and the read-back buffer.  Submissions rotate through the lanes, so the
     // kernels of consecutive MSMs overlap on the GPU: the sort and reduce phases and the accumulate kernel's
     // tail leave CUs idle that the neighbouring MSM's accumulate kernel fills (2^20 points: 1.89 -> 1.73 ms per
     // MSM with three lanes).  Lanes beyond the first are allocated on first use.
@@ -682,9 +681,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, zcount, size_bins, perm, arena, out, heavy_tasks, heavy_buckets,
             heavy_partial;
         PinnedBuf h_out;
-        hipStream_t stream = nullptr, aux = nullptr;
-        hipEvent_t ev_in = nullptr, ev_consumed = nullptr, ev_fork = nullptr, ev_join = nullptr, done = nullptr;
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_consumed = nullptr, done = nullptr;
+        hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling; [5], [6] bracket the accumulate kernel
         bool ready = false, busy = false, empty = false, profiled = false;
         int c = 0;
     };
@@ -735,16 +734,14 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.out.alloc(out_bytes_max);
         L.h_out.alloc(out_bytes_max);
         ZK_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        ZK_HIP(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking));
-        for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.ev_fork, &L.ev_join, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         L.ready = true;
     }
     ~MsmPlanImpl() override {
         for (auto &L : lanes) {
             if (L.stream) (void)hipStreamSynchronize(L.stream);
-            if (L.aux) (void)hipStreamDestroy(L.aux);
             if (L.stream) (void)hipStreamDestroy(L.stream);
-            for (hipEvent_t e : {L.ev_in, L.ev_consumed, L.ev_fork, L.ev_join, L.done})
+            for (hipEvent_t e : {L.ev_in, L.ev_consumed, L.done})
                 if (e) (void)hipEventDestroy(e);
             for (auto &e : L.ev)
                 if (e) (void)hipEventDestroy(e);
@@ -766,7 +763,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                            L.pts_m.template as<PackedAffine<F>>(), L.digits.template as<int16_t>(), L.cells.template as<uint32_t>(), n, n_pad);
     }
     void launch_sort_accumulate(Lane &L, uint32_t n_pad, uint32_t nb, uint32_t W) {
-        hipStream_t st = L.stream, aux = L.aux;
+        hipStream_t st = L.stream;
         const uint32_t G = (nb + SEG_BUCKETS - 1) / SEG_BUCKETS;
         if (G * W > MAX_CELLS) throw std::runtime_error("zk_msm: too many sort cells");
         SortBufs B;
@@ -798,20 +795,19 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((nbuckets_all + 2047) / 2048), dim3(1024), 0, st, B, nbuckets_all);
         mark(L, 2);
-        // heavy buckets (normally none) on the aux stream: the grids cover the worst case and exit on the device-side counters
-        ZK_HIP(hipEventRecord(L.ev_fork, st));
-        ZK_HIP(hipStreamWaitEvent(aux, L.ev_fork, 0));
-        hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, aux, B);
-        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, aux,
-                           L.pts_m.template as<PackedAffine<F>>(), B, L.heavy_partial.template as<Xyzz<F>>());
-        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, aux, B, L.heavy_partial.template as<Xyzz<F>>(),
-                           L.arena.template as<Xyzz<F>>());
-        ZK_HIP(hipEventRecord(L.ev_join, aux));
         const uint32_t nbuckets = W * nb;
+        mark(L, 5);
         hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, L.pts_m.template as<PackedAffine<F>>(),
                            L.sorted.template as<uint32_t>(), L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(),
                            L.perm.template as<uint32_t>(), L.arena.template as<Xyzz<F>>(), nbuckets, B.heavy_th);
-        ZK_HIP(hipStreamWaitEvent(st, L.ev_join, 0));
+        mark(L, 6);
+        // heavy buckets (normally none): the grids cover the worst case and exit on the device-side counters.  Same stream:
+        // a lane's low-occupancy phases are filled by the neighbouring lanes, and the device only has a few hardware queues.
+        hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, st, B);
+        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, st,
+                           L.pts_m.template as<PackedAffine<F>>(), B, L.heavy_partial.template as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, st, B, L.heavy_partial.template as<Xyzz<F>>(),
+                           L.arena.template as<Xyzz<F>>());
     }
 
     // Enqueues the whole GPU pipeline plus the 36 KiB read-back; returns a ticket.  The work runs on the lane's own
@@ -871,7 +867,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         if (L.empty) return Xyzz<HF>::inf();
         ZK_HIP(hipEventSynchronize(L.done));
         if (L.profiled) {
-            for (int i = 0; i < 4; i++) ZK_HIP(hipEventElapsedTime(&stage_ms[i], L.ev[i], L.ev[i + 1]));
+            ZK_HIP(hipEventElapsedTime(&stage_ms[0], L.ev[0], L.ev[1]));
+            ZK_HIP(hipEventElapsedTime(&stage_ms[1], L.ev[1], L.ev[2]));
+            ZK_HIP(hipEventElapsedTime(&stage_ms[2], L.ev[5], L.ev[6]));  // the accumulate kernel alone
+            ZK_HIP(hipEventElapsedTime(&stage_ms[3], L.ev[3], L.ev[4]));
         }
         const int c = L.c;
         const uint32_t W = (255 + c - 1) / c, levels = c - 1;
