@@ -119,6 +119,13 @@ int zk_ntt_plan_destroy(zk_ntt_plan *plan);
 /* In-place transform of a DEVICE buffer of n*4 limbs.  Enqueues on `stream` and returns without
  * synchronising.  coset_shift is a HOST pointer (nullable). */
 int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t coset_shift[4], void *stream);
+/* `batch` independent transforms of the plan's size stored back to back in d_data (no coset shift). */
+int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream);
+/* Twiddle between the two dimensions of a four-step transform of the PLAN's size n = 2^log_n whose second
+ * dimension has 2^log_cols points:  d_data[b * 2^log_cols + k] *= omega_n^(+-(row0 + b) * k)  for b < rows.
+ * Together with zk_ntt_dev_batch this is the local work of the multi-GPU single large NTT
+ * (interactive-zkp-study_amd/zkhip/distributed.py: DistNtt). */
+int zk_ntt_twiddle_dev(zk_ntt_plan *plan, void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, int inverse, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * F_r vector helpers on DEVICE buffers (the pointwise part of the at-scale quotient,

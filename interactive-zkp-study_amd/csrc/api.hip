@@ -432,6 +432,20 @@ int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t cose
         return ZK_OK;
     });
 }
+int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream) {
+    return guarded([&] {
+        if (!plan || (batch && !d_data)) return invalid("zk_ntt_dev_batch: null pointer");
+        plan->impl->run(d_data, inverse != 0, nullptr, (hipStream_t)stream, batch);
+        return ZK_OK;
+    });
+}
+int zk_ntt_twiddle_dev(zk_ntt_plan *plan, void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, int inverse, void *stream) {
+    return guarded([&] {
+        if (!plan || (rows && !d_data)) return invalid("zk_ntt_twiddle_dev: null pointer");
+        plan->impl->twiddle_2d(d_data, log_cols, rows, row0, inverse != 0, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t coset_shift[4]) {
     return guarded([&] {
         if (!data || log_n > 28) return invalid("zk_ntt_fr: bad argument");

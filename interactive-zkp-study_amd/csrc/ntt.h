@@ -1,5 +1,6 @@
 // ntt.h -- internal interface of the F_r NTT pipeline (ntt.hip).
 #pragma once
+#include <stdexcept>
 #include <vector>
 #include "common.h"
 #include "field.h"
@@ -25,7 +26,11 @@ class NttPlan {
   public:
     explicit NttPlan(unsigned log_n);
     // In-place transform of the device buffer (n * 32 bytes, canonical elements).  Enqueues only.
-    void run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st);
+    // `batch` > 1: that many independent transforms stored back to back (no coset shift).
+    void run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st, unsigned batch = 1);
+    // data[b * 2^log_cols + k] *= omega_n^(+-(row0 + b) * k), b < rows: the twiddle between the two dimensions of a
+    // four-step transform of n = 2^log_n points whose second dimension has 2^log_cols points.
+    void twiddle_2d(void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, bool inverse, hipStream_t st);
     unsigned log_n() const { return L_; }
 
   private:

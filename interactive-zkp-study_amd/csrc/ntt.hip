@@ -109,8 +109,10 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     const uint32_t ntw = lp ? (1u << (lp - 1)) : 1u;
     uint32_t *data = lds;
     uint32_t *tw = lds + NL * tile;
-    const uint32_t *in_c = static_cast<const uint32_t *>(in_v);
-    const Fr *in_l = static_cast<const Fr *>(in_v);
+    // blockIdx.y = index of the transform inside a batch of independent, contiguous transforms
+    const size_t boff = (size_t)blockIdx.y << P.L;
+    const uint32_t *in_c = static_cast<const uint32_t *>(in_v) + boff * 8;
+    const Fr *in_l = static_cast<const Fr *>(in_v) + boff;
 
     for (uint32_t i = t; i < ntw; i += NTT_NT) lds_st(tw, ntw, i, tile_tw[(size_t)i << P.tw_shift]);
 
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     }
 
     if (!FINAL) {
-        Fr *out_l = static_cast<Fr *>(out_v);
+        Fr *out_l = static_cast<Fr *>(out_v) + boff;
         const uint32_t sh = P.L - lp - P.sp;
         for (uint32_t e = t; e < tile; e += NTT_NT) {
             const uint32_t k = e >> g, c = e & (G - 1u);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             out_l[(size_t)base_addr + ((size_t)k << P.sp) + c] = x;
         }
     } else {
-        uint32_t *out_c = static_cast<uint32_t *>(out_v);
+        uint32_t *out_c = static_cast<uint32_t *>(out_v) + boff * 8;
         uint32_t kmid = mid_in, lmid_tot = 0;
         if (P.nmid == 1) {
             lmid_tot = P.lmid[0];
@@ -196,6 +198,19 @@ __global__ __launch_bounds__(256) void fr_scale_powers_kernel(uint32_t *__restri
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Fr w = fe_mul(A[i & ((1u << lh) - 1u)], B[i >> lh]);
+    st_canon(x + i * 8, fe_mul(ld_canon(x + i * 8), w));
+}
+
+// x[b * cols + k] *= w^((row0 + b) * k) for b < rows, k < cols, with w^e = A[e & mask] * B[e >> lh] (two-level table of the
+// size-n plan): the twiddle between the two dimensions of a four-step transform of n = (rows of all ranks) * cols points.
+__global__ __launch_bounds__(256) void fr_twiddle_2d_kernel(uint32_t *__restrict__ x, const Fr *__restrict__ A, const Fr *__restrict__ B, uint32_t lh,
+                                                            uint32_t log_cols, uint64_t row0, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t b = i >> log_cols, k = i & (((uint64_t)1 << log_cols) - 1);
+    const uint64_t e = (row0 + b) * k;
+    if (e == 0) return;
+    const Fr w = fe_mul(A[e & (((uint64_t)1 << lh) - 1)], B[e >> lh]);
     st_canon(x + i * 8, fe_mul(ld_canon(x + i * 8), w));
 }
 
@@ -241,7 +256,7 @@ NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     for (uint32_t d : digits_) lmax_ = std::max(lmax_, d);
     lh_ = (L_ + 1) / 2;
     build_tables();
-    if (digits_.size() > 1) tmp_.alloc(((size_t)1 << L_) * sizeof(Fr));
+    // the inter-pass scratch (n * 36 bytes per transform in flight) is allocated by the first run()
     static bool attr_done = false;
     if (!attr_done) {
         const void *fns[4] = {reinterpret_cast<const void *>(&ntt_pass_kernel<false, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<false, false>),
@@ -281,8 +296,15 @@ void NttPlan::coset_tables(const uint64_t k[4], bool inverse) {
     cos_dir_ = (int)inverse;
 }
 
-void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st) {
+void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st, unsigned batch) {
     const size_t n = (size_t)1 << L_;
+    if (batch == 0) return;
+    if (batch > 65535) throw std::runtime_error("zk_ntt: batch must be <= 65535");
+    if (coset_shift && batch != 1) throw std::runtime_error("zk_ntt: coset shifts are not available for batched transforms");
+    if (digits_.size() > 1 && tmp_.bytes < (size_t)batch * n * sizeof(Fr)) {
+        ZK_HIP(hipStreamSynchronize(st));  // the old scratch may still be in use
+        tmp_.alloc((size_t)batch * n * sizeof(Fr));
+    }
     uint32_t *data = static_cast<uint32_t *>(d_data);
     const int dir = inverse ? 1 : 0;
     const unsigned D = (unsigned)digits_.size();
@@ -311,10 +333,10 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
             if (!final_pass) {
                 const Fr *B = (inverse && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
                 if (p == 0)
-                    hipLaunchKernelGGL((ntt_pass_kernel<false, true>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                    hipLaunchKernelGGL((ntt_pass_kernel<false, true>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
                                        twA_[dir].as<Fr>(), B, scale_inv_, P);
                 else
-                    hipLaunchKernelGGL((ntt_pass_kernel<false, false>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                    hipLaunchKernelGGL((ntt_pass_kernel<false, false>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
                                        twA_[dir].as<Fr>(), B, scale_inv_, P);
             } else {
                 P.l1 = (D == 1) ? 0 : digits_[0];
@@ -322,10 +344,10 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
                 for (unsigned q = 0; q < P.nmid; q++) P.lmid[q] = digits_[1 + q];
                 P.apply_scale = (inverse && D == 1) ? 1 : 0;
                 if (D == 1)
-                    hipLaunchKernelGGL((ntt_pass_kernel<true, true>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                    hipLaunchKernelGGL((ntt_pass_kernel<true, true>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
                                        twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
                 else
-                    hipLaunchKernelGGL((ntt_pass_kernel<true, false>), dim3(blocks), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
+                    hipLaunchKernelGGL((ntt_pass_kernel<true, false>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
                                        twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
             }
         }
@@ -334,6 +356,16 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
         coset_tables(coset_shift, true);
         hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_.as<Fr>(), cosB_.as<Fr>(), lh_, n);
     }
+    ZK_HIP(hipGetLastError());
+}
+
+void NttPlan::twiddle_2d(void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, bool inverse, hipStream_t st) {
+    const size_t total = (size_t)rows << log_cols;
+    if (log_cols > L_ || ((row0 + rows) << log_cols) > ((uint64_t)1 << L_)) throw std::runtime_error("zk_ntt_twiddle: block exceeds the transform");
+    if (total == 0) return;
+    const int dir = inverse ? 1 : 0;
+    hipLaunchKernelGGL(fr_twiddle_2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_data), twA_[dir].as<Fr>(),
+                       twB_[dir].as<Fr>(), lh_, log_cols, row0, total);
     ZK_HIP(hipGetLastError());
 }
 

@@ -55,6 +55,8 @@ _PROTOS = {
     "zk_ntt_plan_create": (ctypes.c_int, [ctypes.c_uint, ctypes.POINTER(_VP)]),
     "zk_ntt_plan_destroy": (ctypes.c_int, [_VP]),
     "zk_ntt_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_int, _VP, _VP]),
+    "zk_ntt_dev_batch": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_int, _VP]),
+    "zk_ntt_twiddle_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _VP]),
     "zk_fr_quotient_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "zk_fixed_base_g1": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_fixed_base_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),

@@ -112,6 +112,15 @@ class NttPlan:
         _lib.check(_lib.load().zk_ntt_dev(self._h, d_data, 1 if inverse else 0, None if k is None else _lib.ptr(k), stream))
 
 
+    def run_batch(self, d_data, batch, inverse=False, stream=0):
+        """`batch` independent transforms stored back to back in d_data (zk_ntt_dev_batch)."""
+        _lib.check(_lib.load().zk_ntt_dev_batch(self._h, d_data, int(batch), 1 if inverse else 0, stream))
+
+    def twiddle(self, d_data, log_cols, rows, row0, inverse=False, stream=0):
+        """d_data[b * 2^log_cols + k] *= omega_n^(+-(row0 + b) * k) for b < rows, n = this plan's size (zk_ntt_twiddle_dev)."""
+        _lib.check(_lib.load().zk_ntt_twiddle_dev(self._h, d_data, int(log_cols), int(rows), int(row0), 1 if inverse else 0, stream))
+
+
 def fr_quotient(d_out, d_a, d_b, d_c, zinv, n, stream=0):
     """out[i] = (a[i]*b[i] - c[i]) * zinv on device buffers (zk_fr_quotient_dev)."""
     z = _lib.ints_to_limbs([int(zinv)])

@@ -1,4 +1,5 @@
-"""Multi-GPU MSM: shard by contiguous point chunks, one process per GPU, one tiny all-gather.
+"""Multi-GPU MSM (shard by contiguous point chunks, one tiny all-gather) and the multi-GPU single large NTT
+(four-step, one all-to-all); one process per GPU.
 
 MSM is linear, so rank g computes the full Pippenger pipeline on points [lo_g, hi_g) down to a
 single projective partial sum (128 bytes for G1).  The partials are exchanged with ONE
@@ -74,3 +75,116 @@ def fold_partials(group_id, partials):
 def sharded_msm(group_id, local_partial, device=None, group=None):
     """local_partial: this rank's XYZZ partial (uint64[16|32]) -> the global MSM result on every rank."""
     return fold_partials(group_id, all_gather_partials(local_partial, device=device, group=group))
+
+
+# ------------------------------------------------------------------------------------------------
+# Single large NTT across GPUs (SURVEY.md section 8 row E2, mode 2): four-step with ONE all-to-all.
+#
+# n = n1 * n2 points, index j = j1 * n2 + j2 in, k = k1 + n1 * k2 out:
+#     X[k1 + n1 k2] = sum_j2 w_n2^(j2 k2) * [ w_n^(j2 k1) * sum_j1 x[j1 n2 + j2] w_n1^(j1 k1) ]
+# Layout "block-cyclic BC(m)": rank r owns the elements whose index i satisfies (i mod m) in [r m/R, (r+1) m/R),
+# stored as the row-major matrix [i div m][(i mod m) - r m/R].  The forward transform takes BC(n2) and leaves
+# BC(n1) (the same layout when n1 == n2, i.e. for even log n); the inverse takes BC(n1) back to BC(n2).  Pointwise
+# work between a forward and an inverse transform (the quotient of a prover) is layout-agnostic, and an MSM over
+# BC-distributed scalars only needs its points distributed the same way.
+#   1. local: n2/R column transforms of length n1 (transpose, zk_ntt_dev_batch)
+#   2. local: twiddle w_n^(j2 k1)                                  (zk_ntt_twiddle_dev)
+#   3. ONE all-to-all: rank r sends rank s the k1-block of s of its columns (n/R^2 elements per pair; every
+#      pair of GPUs has its own xGMI link, so all links carry traffic at once)
+#   4. local: n1/R row transforms of length n2 (zk_ntt_dev_batch), transpose to [k2][k1 local]
+class _HipLocal:
+    """The local kernels of DistNtt on this process's GPU."""
+
+    def __init__(self, log_n, l1, l2):
+        from .device import NttPlan
+        self.p1, self.p2 = NttPlan(l1), NttPlan(l2)
+        self.pn = NttPlan(log_n)  # twiddle tables of the full size (its scratch is never allocated)
+
+    def ntt_rows(self, t, which, inverse):
+        """t: (batch, len, 4) int64 contiguous device tensor, transformed in place along dim 1."""
+        import torch
+        plan = self.p1 if which == 1 else self.p2
+        plan.run_batch(t.data_ptr(), t.shape[0], inverse, torch.cuda.current_stream().cuda_stream)
+
+    def twiddle(self, t, row0, inverse):
+        """t: (rows, cols, 4): t[b, k] *= w_n^(+-(row0 + b) k)."""
+        import torch
+        self.pn.twiddle(t.data_ptr(), t.shape[1].bit_length() - 1, t.shape[0], row0, inverse, torch.cuda.current_stream().cuda_stream)
+
+
+class DistNtt:
+    """Forward / inverse NTT of 2^log_n points spread over the ranks of a process group (see the comment above).
+
+    `local` supplies ntt_rows / twiddle; the default runs the HIP kernels (tests inject the oracle to
+    exercise the layout logic and the collective on CPU)."""
+
+    def __init__(self, log_n, group=None, l1=None, local=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.log_n = int(log_n)
+        self.l1 = int(l1) if l1 is not None else self.log_n // 2
+        if not 0 <= self.l1 <= self.log_n:
+            raise ValueError("DistNtt: l1 must lie in [0, log_n]")
+        self.l2 = self.log_n - self.l1
+        self.n1, self.n2 = 1 << self.l1, 1 << self.l2
+        R = self.world
+        if R & (R - 1) or self.n1 % R or self.n2 % R:
+            raise ValueError("DistNtt: the world size must be a power of two dividing both 2^l1 and 2^l2")
+        self.c, self.k = self.n2 // R, self.n1 // R  # local columns (forward input) / local rows (forward output)
+        self.local = local if local is not None else _HipLocal(self.log_n, self.l1, self.l2)
+
+    # layouts ------------------------------------------------------------------------------------
+    def local_shape_in(self):
+        return (self.n1, self.c)      # BC(n2): [j1][j2 local]
+
+    def local_shape_out(self):
+        return (self.n2, self.k)      # BC(n1): [k2][k1 local]
+
+    def scatter_in(self, full):
+        """Natural-order array (n, 4) -> this rank's BC(n2) block (n1, c, 4) (test / setup helper)."""
+        return full.reshape(self.n1, self.n2, 4)[:, self.rank * self.c:(self.rank + 1) * self.c].copy()
+
+    def scatter_out(self, full):
+        return full.reshape(self.n2, self.n1, 4)[:, self.rank * self.k:(self.rank + 1) * self.k].copy()
+
+    # transforms ---------------------------------------------------------------------------------
+    def _exchange(self, send):
+        """send: (R, a, b, 4) contiguous, block s goes to rank s -> (R, a, b, 4) with block r received from rank r."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return send
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":   # rehearsal of several ranks on one GPU: stage through the host
+            h_send = send.cpu()
+            h_recv = torch.empty_like(h_send)
+            dist.all_to_all_single(h_recv.view(-1), h_send.view(-1), group=self.group)
+            return h_recv.to(send.device)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        return recv
+
+    def forward(self, x):
+        """x: (n1, c, 4) int64 tensor, this rank's BC(n2) block -> (n2, k, 4), its BC(n1) block of the transform."""
+        R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
+        cols = x.permute(1, 0, 2).contiguous()                        # [c][j1]
+        self.local.ntt_rows(cols, 1, False)                           # [c][k1]
+        self.local.twiddle(cols, self.rank * c, False)                # * w_n^(j2 k1), j2 = rank*c + c_local
+        send = cols.view(c, R, k, 4).permute(1, 0, 2, 3).contiguous()  # [s][c][k1 local of s]
+        recv = self._exchange(send)                                   # [r][c][k1 local]  ==  [j2][k1 local]
+        rows = recv.view(n2, k, 4).permute(1, 0, 2).contiguous()      # [k1 local][j2]
+        self.local.ntt_rows(rows, 2, False)                           # [k1 local][k2]
+        return rows.permute(1, 0, 2).contiguous()                     # [k2][k1 local]
+
+    def inverse(self, y):
+        """y: (n2, k, 4), a BC(n1) block -> (n1, c, 4), the BC(n2) block of the inverse transform (1/n included)."""
+        R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
+        rows = y.permute(1, 0, 2).contiguous()                        # [k1 local][k2]
+        self.local.ntt_rows(rows, 2, True)                            # [k1 local][j2]   (1/n2 applied)
+        send = rows.view(k, R, c, 4).permute(1, 2, 0, 3).contiguous()  # [s][c local of s][k1 local]
+        recv = self._exchange(send)                                   # [r][c][k1 local of r]
+        cols = recv.permute(1, 0, 2, 3).contiguous().view(c, n1, 4)   # [c][k1]
+        self.local.twiddle(cols, self.rank * c, True)                 # * w_n^(-j2 k1)
+        self.local.ntt_rows(cols, 1, True)                            # [c][j1]          (1/n1 applied)
+        return cols.permute(1, 0, 2).contiguous()                     # [j1][c]
