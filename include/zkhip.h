@@ -86,10 +86,12 @@ int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_p
                        uint64_t *out_xyzz, void *stream);
 /* Pipelined form of the two calls above: zk_msm_submit enqueues the whole GPU pipeline (and the
  * 36 KiB read-back) and returns at once with a ticket; zk_msm_collect / _collect_partial wait for
- * that submission and do the host fold.  Up to zk_msm_plan_max_in_flight(plan) submissions (3 for
- * plans of <= 2^22 points, else 2) may be outstanding; each runs in its own workspace and stream, so
- * consecutive MSMs overlap on the GPU and the host fold of MSM k hides behind MSM k+1 (a prover
- * issues 5-17 MSMs back to back).  Tickets are collected in any order. */
+ * that submission and do the host fold.  Up to zk_msm_plan_max_in_flight(plan) (3) submissions may be
+ * outstanding; each runs in its own workspace and stream, so consecutive MSMs overlap on the GPU and
+ * the host fold of MSM k hides behind MSM k+1 (a prover issues 5-17 MSMs back to back).  Tickets are
+ * collected in any order.  An MSM of more than 2^22 points runs as consecutive 2^22-point chunks in
+ * those same lanes (partial sums added on the host): it needs all lanes free, zk_msm_submit may block
+ * for its early chunks, and it is the only submission outstanding until collected. */
 int zk_msm_plan_max_in_flight(const zk_msm_plan *plan);
 int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket);
 int zk_msm_collect(zk_msm_plan *plan, int ticket, uint64_t *out_xy, int *out_is_inf);

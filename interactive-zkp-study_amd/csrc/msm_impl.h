@@ -691,13 +691,32 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     Lane lanes[MAX_LANES];
     int nlanes = 1, next_lane = 0;
 
+    // MSMs beyond 2^22 points are run as consecutive chunks of 2^22 (each in its own lane, partial sums added on the
+    // host): the packed bases of a chunk (256 MB) stay within reach of the Infinity Cache and the TLB -- at 2^26 in one
+    // piece the gathers of the accumulate kernel run 40 % slower -- and the chunks overlap like any other submissions
+    // (2^24: 26.3 -> 24.0 ms, 2^26: 138 -> 93 ms).  The workspace never exceeds that of a 2^22-point MSM.
+    static size_t chunk_points() {  // ZK_MSM_CHUNK_LOG: test knob (chunking at sizes the oracle can check)
+        const char *e = getenv("ZK_MSM_CHUNK_LOG");
+        const int l = e ? atoi(e) : 22;
+        return (size_t)1 << (l < 12 ? 12 : l > 24 ? 24 : l);
+    }
+    static constexpr int BIG_TICKET = 64;
+    size_t cap_n = 0;
+    struct {
+        bool active = false;
+        Xyzz<HF> acc;
+        int pend[8];
+        int npend = 0;
+    } big;
+
     explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
         group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
-        const size_t n_pad = pad_n(max_n);
+        cap_n = std::min(max_n, chunk_points());
+        const size_t n_pad = pad_n(cap_n);
         // worst case over the window choices available to n <= max_n
         const int cs[5] = {8, 10, 13, 15, 16};
         for (int c : cs) {
-            if (c > pick_window_bits(max_n)) continue;
+            if (c > pick_window_bits(cap_n)) continue;
             size_t W = (255 + c - 1) / c, nb = (size_t)1 << (c - 1);
             dig_bytes = std::max(dig_bytes, W * n_pad * sizeof(int16_t));
             arena_bytes = std::max(arena_bytes, W * nb * sizeof(Xyzz<F>));
@@ -706,14 +725,13 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         // heavy-bucket scratch: a heavy bucket holds > heavy_th >= HEAVY_SEG entries, so there are < entries / HEAVY_SEG of
         // them and sum ceil(len / HEAVY_WAVE) <= entries / HEAVY_WAVE + (heavy buckets) wavefront tasks; entries <= W * n_pad
         heavy_cap = (uint32_t)(dig_bytes / sizeof(int16_t) / HEAVY_SEG + dig_bytes / sizeof(int16_t) / HEAVY_WAVE + 64);
-        // beyond 2^22 points a single MSM fills the chip for tens of ms and the workspace runs to GBs: two lanes
-        nlanes = max_n <= ((size_t)1 << 22) ? 3 : 2;
+        nlanes = 3;
         prepare_lane(lanes[0]);
     }
     void prepare_lane(Lane &L) {
         if (L.ready) return;
         const size_t dig = dig_bytes, nbk = arena_bytes / sizeof(Xyzz<F>);
-        L.pts_m.alloc(max_n * sizeof(PackedAffine<F>));
+        L.pts_m.alloc(cap_n * sizeof(PackedAffine<F>));
         L.digits.alloc(dig);
         const size_t span_slack = (size_t)MAX_CELLS * 16 + 64;  // cell spans are padded to 16 entries
         L.sorted.alloc(dig * 2 + span_slack * 4);               // one 4-byte entry per (window, point)
@@ -815,6 +833,31 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // kernel has consumed the caller's scalars and points (the only kernel that reads them).
     int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) override {
         if (n > max_n) throw std::runtime_error("zk_msm: n exceeds the plan's max_n");
+        if (big.active) throw std::runtime_error("zk_msm: a chunked (> 2^22 points) submission is outstanding; collect it first");
+        if (n > cap_n) return submit_chunked(d_scalars, d_points, n, st);
+        return submit_lane(d_scalars, d_points, n, st);
+    }
+    // n > CHUNK: every chunk is an ordinary submission; when the lanes run out the oldest chunk is collected (this call
+    // then blocks for it).  The ticket stands for the whole MSM; no other submission may be outstanding meanwhile.
+    int submit_chunked(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
+        for (int i = 0; i < nlanes; i++)
+            if (lanes[i].busy) throw std::runtime_error("zk_msm: an MSM of more than 2^22 points needs all lanes free; collect first");
+        big.active = true;
+        big.acc = Xyzz<HF>::inf();
+        big.npend = 0;
+        const uint32_t *sc = static_cast<const uint32_t *>(d_scalars), *pt = static_cast<const uint32_t *>(d_points);
+        for (size_t off = 0; off < n; off += cap_n) {
+            const size_t m = std::min(cap_n, n - off);
+            if (big.npend == nlanes) {
+                xyzz_add(big.acc, collect_lane(big.pend[0]));
+                for (int i = 1; i < big.npend; i++) big.pend[i - 1] = big.pend[i];
+                big.npend--;
+            }
+            big.pend[big.npend++] = submit_lane(sc + off * 8, pt + off * 2 * F::CANON_WORDS, m, st);
+        }
+        return BIG_TICKET;
+    }
+    int submit_lane(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
         const int ticket = next_lane;
         Lane &L = lanes[ticket];
         if (L.busy) throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect the oldest first");
@@ -861,6 +904,15 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
 
     // Waits for a submission and folds its window/level sums on the host.
     Xyzz<HF> collect(int ticket) {
+        if (ticket == BIG_TICKET && big.active) {
+            for (int i = 0; i < big.npend; i++) xyzz_add(big.acc, collect_lane(big.pend[i]));
+            big.active = false;
+            big.npend = 0;
+            return big.acc;
+        }
+        return collect_lane(ticket);
+    }
+    Xyzz<HF> collect_lane(int ticket) {
         if (ticket < 0 || ticket >= nlanes || !lanes[ticket].busy) throw std::runtime_error("zk_msm: bad ticket");
         Lane &L = lanes[ticket];
         L.busy = false;

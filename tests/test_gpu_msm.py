@@ -291,3 +291,29 @@ def test_fixed_base_batches_bit_exact(n):
     zero = np.zeros((1, 8), dtype=np.uint64)
     _lib.check(lib.zk_fixed_base_g1(_lib.ptr(zero), _lib.ptr(K), n, _lib.ptr(out1)))
     assert not out1.any()
+
+
+def test_chunked_msm_small_chunks(monkeypatch):
+    """MSMs beyond the chunk size (2^24 points; here 2^12 through the test knob) run as consecutive chunks in the
+    plan's lanes with the partial sums added on the host: blocking, pipelined and partial forms, bit-exact."""
+    import torch
+    monkeypatch.setenv("ZK_MSM_CHUNK_LOG", "12")
+    rng = np.random.default_rng(31)
+    n = 5 * 4096 + 123
+    S = rand_fr_limbs(rng, n)
+    Pts, _ = rand_g1_limbs(rng, n)
+    want = co.g1_msm_bucket_arr(S, Pts, 12)
+    dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    got = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), n, st)[0]
+    assert np.array_equal(got, want)
+    t = plan.submit(dS.data_ptr(), dP.data_ptr(), n, st)
+    with pytest.raises(_lib.ZkhipError):
+        plan.submit(dS.data_ptr(), dP.data_ptr(), 100, st)       # nothing else while a chunked MSM is outstanding
+    assert np.array_equal(plan.collect_limbs(t)[0], want)
+    part = plan.run_partial(dS.data_ptr(), dP.data_ptr(), n, st)
+    assert np.array_equal(_lib.limbs_to_ints(np.array(co.g1_to_arr([fold_partials(_lib.GROUP_G1, part)]))), _lib.limbs_to_ints(want.reshape(1, 8)))
+    small = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), 3000, st)[0]  # below the chunk size: the ordinary path
+    assert np.array_equal(small, co.g1_msm_arr(S[:3000], Pts[:3000]))
+    plan.close()
