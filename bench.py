@@ -124,7 +124,7 @@ def main():
             return plan.collect_limbs(ticket)
         return sharded_msm(_lib.GROUP_G1, plan.collect_partial(ticket), device=dev)
 
-    depth = plan.max_in_flight()
+    depth = plan.max_in_flight() if n <= (1 << 22) else 1   # larger MSMs already run as 2^22-point chunks through all lanes
 
     def run_steps(k, stage_acc=None):
         res, pending = None, []
