@@ -120,6 +120,23 @@ def test_g2_msm_bit_exact_vs_oracle(n):
     assert np.array_equal(msm_g2(S, Pts), co.g2_msm_arr(S, Pts))
 
 
+@pytest.mark.parametrize("pattern", ["all_equal", "witness_like"])
+def test_g2_msm_skewed_scalars(pattern):
+    """The heavy-bucket kernels and the multi-workgroup cell sort in their F_p^2 instantiation."""
+    rng = np.random.default_rng(17)
+    n = 3000
+    base, _ = rand_g2_limbs(rng, 24)
+    Pts = base[rng.integers(0, 24, size=n)]                      # few distinct points, many repeats: doublings inside buckets too
+    if pattern == "all_equal":
+        S = np.tile(rand_fr_limbs(rng, 1), (n, 1))
+    else:
+        S = rand_fr_limbs(rng, n)
+        pick = rng.integers(0, 4, size=n)
+        S[pick == 0] = 0
+        S[pick == 1] = limb_row(1)
+    assert np.array_equal(msm_g2(S, Pts), co.g2_msm_arr(S, Pts))
+
+
 def test_device_plan_reuse_partials_and_profile():
     import torch
     rng = np.random.default_rng(12)
