@@ -19,6 +19,7 @@ struct NttPassParams {
     uint32_t tw_shift;   // in-tile twiddle table stride shift (lmax - lp)
     uint32_t lh;         // low-part bits of the two-level inter-pass twiddle tables
     uint32_t apply_scale;  // final pass: multiply outputs by `scale` (D == 1 inverse)
+    uint32_t direct_tw;    // inter-pass twiddles come ready-made from a per-(k, rem) table instead of the two-level one
 };
 
 // Natural-order in/out radix-2 NTT over F_r of size 2^log_n; omega = 5^((r-1)/n).
@@ -42,6 +43,7 @@ class NttPlan {
     DevBuf tmp_;
     // [0] forward, [1] inverse
     DevBuf tile_tw_[2], twA_[2], twB_[2], twB_scaled_inv_;
+    DevBuf tw_direct_[2][3];  // ready-made inter-pass twiddles of the small pass boundaries
     Fr scale_inv_;  // n^-1 (Montgomery)
     // coset power tables (two-level), cached for the last (k, direction)
     DevBuf cosA_, cosB_;

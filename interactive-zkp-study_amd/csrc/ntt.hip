@@ -167,7 +167,9 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             Fr x = lds_ld(data, tile, (jpos << g) | c);
             const uint32_t rem = (mid << g) + c;
             const uint32_t ex = (k * rem) << sh;
-            const Fr w = fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);   // table entries < r
+            // small boundaries keep the ready-made twiddle per (k, rem) (cache-resident table); large ones build it from the
+            // two-level table with one extra multiplication
+            const Fr w = P.direct_tw ? twA[((size_t)k << P.sp) + rem] : fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);  // < 2r
             x = fe_mul(x, w);                                                      // 2 * 2 < 169  ->  < 2r
             out_l[(size_t)base_addr + ((size_t)k << P.sp) + c] = x;
         }
@@ -212,6 +214,16 @@ __global__ __launch_bounds__(256) void fr_twiddle_2d_kernel(uint32_t *__restrict
     if (e == 0) return;
     const Fr w = fe_mul(A[e & (((uint64_t)1 << lh) - 1)], B[e >> lh]);
     st_canon(x + i * 8, fe_mul(ld_canon(x + i * 8), w));
+}
+
+// out[(k << sp) + rem] = w^((k * rem) << sh) from the two-level table: the ready-made inter-pass twiddles of one pass.
+__global__ __launch_bounds__(256) void ntt_direct_table_kernel(Fr *__restrict__ out, const Fr *__restrict__ A, const Fr *__restrict__ B, uint32_t lh,
+                                                               uint32_t sp, uint32_t sh, uint32_t total) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t k = i >> sp, rem = i & ((1u << sp) - 1u);
+    const uint32_t ex = (k * rem) << sh;
+    out[i] = fe_mul(A[ex & ((1u << lh) - 1u)], B[ex >> lh]);
 }
 
 __global__ __launch_bounds__(256) void fr_quotient_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
@@ -282,6 +294,21 @@ void NttPlan::build_tables() {
         upload_powers(twB_[dir], bh, (size_t)1 << (L_ - lh_));
         if (dir) upload_powers(twB_scaled_inv_, bh, (size_t)1 << (L_ - lh_), &ninv);
     }
+    // ready-made twiddles for the pass boundaries whose table is small (<= 2^20 entries, 36 MB: cache-resident)
+    for (int dir = 0; dir < 2; dir++) {
+        uint32_t sp = L_;
+        for (size_t p = 0; p + 1 < digits_.size() && p < 3; p++) {
+            const uint32_t lp = digits_[p];
+            sp -= lp;
+            if (lp + sp > 20) continue;
+            const uint32_t total = 1u << (lp + sp), sh = L_ - lp - sp;
+            tw_direct_[dir][p].alloc((size_t)total * sizeof(Fr));
+            const Fr *B = (dir == 1 && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
+            hipLaunchKernelGGL(ntt_direct_table_kernel, dim3((total + 255) / 256), dim3(256), 0, 0, tw_direct_[dir][p].as<Fr>(), twA_[dir].as<Fr>(), B, lh_,
+                               sp, sh, total);
+        }
+    }
+    ZK_HIP(hipDeviceSynchronize());
 }
 
 void NttPlan::coset_tables(const uint64_t k[4], bool inverse) {
@@ -332,12 +359,17 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
             const unsigned blocks = (unsigned)(n >> (lp + P.g));
             if (!final_pass) {
                 const Fr *B = (inverse && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
+                const Fr *A = twA_[dir].as<Fr>();
+                if (p < 3 && tw_direct_[dir][p].p) {
+                    P.direct_tw = 1;
+                    A = tw_direct_[dir][p].as<Fr>();
+                }
                 if (p == 0)
-                    hipLaunchKernelGGL((ntt_pass_kernel<false, true>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
-                                       twA_[dir].as<Fr>(), B, scale_inv_, P);
+                    hipLaunchKernelGGL((ntt_pass_kernel<false, true>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B,
+                                       scale_inv_, P);
                 else
-                    hipLaunchKernelGGL((ntt_pass_kernel<false, false>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
-                                       twA_[dir].as<Fr>(), B, scale_inv_, P);
+                    hipLaunchKernelGGL((ntt_pass_kernel<false, false>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B,
+                                       scale_inv_, P);
             } else {
                 P.l1 = (D == 1) ? 0 : digits_[0];
                 P.nmid = D > 2 ? D - 2 : 0;
