@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             Fr x = lds_ld(data, tile, (jpos << g) | c);
             const uint32_t rem = (mid << g) + c;
             const uint32_t ex = (k * rem) << sh;
-            // small boundaries keep the ready-made twiddle per (k, rem) (cache-resident table); large ones build it from the
+            // boundaries up to 2^24 entries keep the ready-made twiddle per (k, rem); larger ones build it from the
             // two-level table with one extra multiplication
             const Fr w = P.direct_tw ? twA[((size_t)k << P.sp) + rem] : fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);  // < 2r
             x = fe_mul(x, w);                                                      // 2 * 2 < 169  ->  < 2r
@@ -294,13 +294,13 @@ void NttPlan::build_tables() {
         upload_powers(twB_[dir], bh, (size_t)1 << (L_ - lh_));
         if (dir) upload_powers(twB_scaled_inv_, bh, (size_t)1 << (L_ - lh_), &ninv);
     }
-    // ready-made twiddles for the pass boundaries whose table is small (<= 2^20 entries, 36 MB: cache-resident)
+    // ready-made twiddles for the pass boundaries whose table has <= 2^24 entries (576 MB; beyond, the two-level table)
     for (int dir = 0; dir < 2; dir++) {
         uint32_t sp = L_;
         for (size_t p = 0; p + 1 < digits_.size() && p < 3; p++) {
             const uint32_t lp = digits_[p];
             sp -= lp;
-            if (lp + sp > 20) continue;
+            if (lp + sp > 24) continue;
             const uint32_t total = 1u << (lp + sp), sh = L_ - lp - sp;
             tw_direct_[dir][p].alloc((size_t)total * sizeof(Fr));
             const Fr *B = (dir == 1 && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
