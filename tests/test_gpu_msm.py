@@ -282,6 +282,19 @@ def test_g1_msm_2pow20_closed_form_and_linearity():
     assert co.g1_from_arr(d)[0] == co.g1_add(co.g1_from_arr(a)[0], co.g1_from_arr(a)[0])
 
 
+def test_g1_msm_2pow20_bit_exact_vs_oracle_pippenger():
+    """BASELINE.json configs[1] in full: 2^20 random scalars x points, the GPU result against the oracle's serial
+    bucket-method MSM (a structurally different restatement: unsigned windows, Jacobian, running sums) -- bit-exact."""
+    from bench import random_scalars
+    rng = np.random.default_rng(2020)
+    n = 1 << 20
+    S, K = random_scalars(rng, n), random_scalars(rng, n)
+    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+    Pts = np.zeros((n, 8), dtype=np.uint64)
+    _lib.check(_lib.load().zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(K), n, _lib.ptr(Pts)))
+    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_bucket_arr(S, Pts, 15))
+
+
 @pytest.mark.parametrize("n", [5, 4096, 5000])
 def test_fixed_base_batches_bit_exact(n):
     """zk_fixed_base_g1/g2 (setup.py:18-69, srs.py:77-85): below 4096 scalars one double-and-add per thread, from

@@ -111,6 +111,19 @@ def test_ntt_2pow22_round_trip_and_horner():
     assert np.array_equal(d.cpu().numpy().view(np.uint64), X)
 
 
+def test_ntt_2pow22_bit_exact_vs_oracle():
+    """BASELINE.json configs[2] in full: every one of the 2^22 outputs against the oracle's recursive radix-2 NTT."""
+    import torch
+    rng = np.random.default_rng(2222)
+    L = 22
+    n = 1 << L
+    X = _fast_rand(rng, n)
+    d = torch.from_numpy(X.view(np.int64).copy()).cuda()
+    NttPlan(L).run(d.data_ptr(), False, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), co.ntt_arr(X, o.get_root_of_unity(n), False))
+
+
 def test_ntt_linearity_2pow18():
     rng = np.random.default_rng(16)
     n = 1 << 18
