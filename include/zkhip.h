@@ -136,6 +136,13 @@ int zk_ntt_twiddle_dev(zk_ntt_plan *plan, void *d_data, unsigned log_cols, uint6
  */
 int zk_fr_quotient_dev(void *d_out, const void *d_a, const void *d_b, const void *d_c,
                        const uint64_t zinv[4], size_t n, void *stream);
+/*
+ *   y = M x over F_r for a CSR matrix (u32 row_ptr[rows+1], u32 col[nnz], vals[nnz*4 limbs]): the scalar
+ *   collapse A.w, B.w, C.w of an R1CS with its witness, which zkp/groth16/proving.py:27-31 carries out in
+ *   the group (W*G scalar multiplications).
+ */
+int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals, const void *d_x, void *d_y,
+                   size_t rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fixed-base batch scalar multiplication out[i] = scalars[i] * base  (HOST buffers).

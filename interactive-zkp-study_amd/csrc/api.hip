@@ -462,6 +462,13 @@ int zk_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t coset_
         return ZK_OK;
     });
 }
+int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals, const void *d_x, void *d_y, size_t rows, void *stream) {
+    return guarded([&] {
+        if (rows && (!d_row_ptr || !d_col || !d_vals || !d_x || !d_y)) return invalid("zk_fr_spmv_dev: null pointer");
+        fr_spmv(d_row_ptr, d_col, d_vals, d_x, d_y, rows, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_fr_quotient_dev(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, void *stream) {
     return guarded([&] {
         if (!d_out || !d_a || !d_b || !d_c || !zinv) return invalid("zk_fr_quotient_dev: null pointer");

@@ -51,6 +51,9 @@ class NttPlan {
     int cos_dir_ = -1;
 };
 
+// y = M x for a CSR matrix over F_r (u32 row_ptr[rows+1], u32 col[nnz], canonical vals[nnz], x, y) on device buffers.
+void fr_spmv(const void *d_row_ptr, const void *d_col, const void *d_vals, const void *d_x, void *d_y, size_t rows, hipStream_t st);
+
 // out[i] = (a[i]*b[i] - c[i]) * zinv  on device buffers of canonical F_r elements.
 void fr_quotient(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, hipStream_t st);
 

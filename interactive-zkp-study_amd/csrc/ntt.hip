@@ -235,6 +235,22 @@ __global__ __launch_bounds__(256) void fr_quotient_kernel(uint32_t *__restrict__
     st_canon(out + i * 8, fe_sub_k<2>(ab, fe_mul(ld_canon(c + i * 8), zr)));
 }
 
+// y[i] = sum_{j in row i} vals[j] * x[col[j]]  (CSR, canonical elements): the F_r mat-vec that collapses the
+// witness into the per-constraint values A.w, B.w, C.w (zkp/groth16/proving.py:27-31 does this product in the
+// group, W*G scalar multiplications).  R1CS rows hold a handful of entries: one thread per row.
+__global__ __launch_bounds__(256) void fr_spmv_kernel(const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ vals,
+                                                      const uint32_t *__restrict__ x, uint32_t *__restrict__ y, size_t rows) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    Fr acc = Fr::zero();
+    for (uint32_t j = row_ptr[i], e = row_ptr[i + 1]; j < e; j++) {
+        const Fr v = fe_to_mont(ld_canon(vals + (size_t)j * 8));              // v * R
+        acc = fe_add(acc, fe_mul(v, ld_canon(x + (size_t)col[j] * 8)));        // v * x  (< 2r), running sum < 4r
+        fe_wreduce<4>(acc);                                                    // < 2r
+    }
+    st_canon(y + i * 8, acc);
+}
+
 // ------------------------------------------------------------------------------ host side
 static HFr hfr_pow_u64(HFr a, uint64_t e) {
     uint64_t ee[4] = {e, 0, 0, 0};
@@ -398,6 +414,14 @@ void NttPlan::twiddle_2d(void *d_data, unsigned log_cols, uint64_t rows, uint64_
     const int dir = inverse ? 1 : 0;
     hipLaunchKernelGGL(fr_twiddle_2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_data), twA_[dir].as<Fr>(),
                        twB_[dir].as<Fr>(), lh_, log_cols, row0, total);
+    ZK_HIP(hipGetLastError());
+}
+
+void fr_spmv(const void *d_row_ptr, const void *d_col, const void *d_vals, const void *d_x, void *d_y, size_t rows, hipStream_t st) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(fr_spmv_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, static_cast<const uint32_t *>(d_row_ptr),
+                       static_cast<const uint32_t *>(d_col), static_cast<const uint32_t *>(d_vals), static_cast<const uint32_t *>(d_x),
+                       static_cast<uint32_t *>(d_y), rows);
     ZK_HIP(hipGetLastError());
 }
 

@@ -58,6 +58,7 @@ _PROTOS = {
     "zk_ntt_dev_batch": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_int, _VP]),
     "zk_ntt_twiddle_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _VP]),
     "zk_fr_quotient_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
+    "zk_fr_spmv_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "zk_fixed_base_g1": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_fixed_base_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_group_op": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, _VP, _SZ, _VP]),

@@ -125,3 +125,8 @@ def fr_quotient(d_out, d_a, d_b, d_c, zinv, n, stream=0):
     """out[i] = (a[i]*b[i] - c[i]) * zinv on device buffers (zk_fr_quotient_dev)."""
     z = _lib.ints_to_limbs([int(zinv)])
     _lib.check(_lib.load().zk_fr_quotient_dev(d_out, d_a, d_b, d_c, _lib.ptr(z), n, stream))
+
+
+def fr_spmv(d_row_ptr, d_col, d_vals, d_x, d_y, rows, stream=0):
+    """y = M x over F_r, M in CSR form on device buffers (zk_fr_spmv_dev)."""
+    _lib.check(_lib.load().zk_fr_spmv_dev(d_row_ptr, d_col, d_vals, d_x, d_y, rows, stream))

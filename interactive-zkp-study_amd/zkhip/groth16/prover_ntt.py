@@ -67,6 +67,20 @@ class ChainCircuit:
         c = [(t[k + 1] - t[k] - self.consts[k]) % R for k in range(self.m)]
         return w, a, list(a), c
 
+    def r1cs_csr(self):
+        """The R1CS matrices in CSR form, {name: (row_ptr u32[m+1], col u32[nnz], vals (nnz, 4) u64 limbs)}:
+        row k:  A = B = e_{1+k};  C = e_{2+k} - e_{1+k} - c_k * e_0."""
+        m = self.m
+        k = np.arange(m, dtype=np.uint32)
+        one = np.zeros((m, 4), dtype=np.uint64)
+        one[:, 0] = 1
+        ab = (np.arange(m + 1, dtype=np.uint32), 1 + k, one)
+        col_c = np.stack([2 + k, 1 + k, np.zeros(m, dtype=np.uint32)], axis=1).reshape(-1)
+        minus_one = _lib.ints_to_limbs([R - 1])[0]
+        minus_c = _lib.ints_to_limbs([(-c) % R for c in self.consts])
+        vals_c = np.stack([one, np.tile(minus_one, (m, 1)), minus_c], axis=1).reshape(-1, 4)
+        return {"A": ab, "B": ab, "C": (3 * np.arange(m + 1, dtype=np.uint32), col_c.astype(np.uint32), vals_c)}
+
     def lagrange_at(self, x):
         """[L_k(x)] for the domain H = {w^k}: L_k(x) = (x^m - 1)/m * w^k / (x - w^k)."""
         m = self.m
@@ -203,6 +217,24 @@ class ScaleProver:
         # proving.py:47-75 with the +-r*s*delta terms cancelled:  s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H
         proof_c = msm_g1([s, r, 1, 1], [proof_a, msm_b1, msm_l, msm_h])
         return proof_a, proof_b, proof_c, h
+
+    def load_r1cs(self, csr):
+        """Uploads the R1CS (dict name -> CSR triple, see ChainCircuit.r1cs_csr) for prove_from_witness."""
+        import torch
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else np.int64)).cuda()
+        self.r1cs = {k: tuple(up(x) for x in v) for k, v in csr.items()}
+        self.abc = [torch.empty((self.m, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+
+    def prove_from_witness(self, d_w, r, s, stream=None):
+        """Witness (W, 4) on the device -> proof: the scalar collapse A.w, B.w, C.w (zk_fr_spmv_dev; the reference's
+        proving.py:27-31 does it in the group), then prove()."""
+        import torch
+        from ..device import fr_spmv
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        for name, out in zip("ABC", self.abc):
+            rp, col, vals = self.r1cs[name]
+            fr_spmv(rp.data_ptr(), col.data_ptr(), vals.data_ptr(), d_w.data_ptr(), out.data_ptr(), self.m, st)
+        return self.prove(self.abc[0], self.abc[1], self.abc[2], d_w, r, s, stream)
 
     @staticmethod
     def _pt(plan, res):

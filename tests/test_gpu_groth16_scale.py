@@ -33,6 +33,10 @@ def test_scale_prover_closed_form(log_m):
     assert pa == ec_mul(G1, A)
     assert pb == ec_mul(G2, B)
     assert pc == ec_mul(G1, C)
+    # the same proof from the witness alone: A.w, B.w, C.w by the device mat-vec (prove() consumed d_a..d_c in place)
+    prover.load_r1cs(circ.r1cs_csr())
+    qa, qb, qc, _ = prover.prove_from_witness(d_w, r, s)
+    assert (qa, qb, qc) == (pa, pb, pc)
     torch.cuda.synchronize()
     hc = _lib.limbs_to_ints(h.cpu().numpy().view(np.uint64))
     assert hc[circ.m - 1] == 0                                   # deg H <= m - 2
