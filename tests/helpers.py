@@ -10,9 +10,21 @@ def rand_fr_limbs(rng, n):
 
 
 def rand_g1_limbs(rng, n):
-    """n random G1 points k_i*G1 (C oracle fixed base) -> ((n,8) limbs, (n,4) k limbs)."""
-    ks = rand_fr_limbs(rng, n)
-    return co.g1_fixed_base_arr(pr.G1, ks), ks
+    """n random G1 points k_i*G1 from the C oracle -> ((n,8) limbs, (n,4) k limbs).  Up to 4096 points every one is an
+    oracle scalar multiplication; beyond, sums of two members of a 1024-point pool (oracle additions, ~100x cheaper)."""
+    if n <= 4096:
+        ks = rand_fr_limbs(rng, n)
+        return co.g1_fixed_base_arr(pr.G1, ks), ks
+    pool_k = [int.from_bytes(rng.bytes(32), "little") % pr.R for _ in range(1024)]
+    pool = co.g1_fixed_base_arr(pr.G1, co.to_limbs(pool_k))
+    ia, ib = rng.integers(0, 1024, size=n), rng.integers(0, 1024, size=n)
+    out = np.zeros((n, 8), dtype=np.uint64)
+    lib = co.lib()
+    tmp = np.zeros(8, dtype=np.uint64)
+    for t in range(n):
+        lib.orc_g1_add(co._p(pool[ia[t]]), co._p(pool[ib[t]]), co._p(tmp))
+        out[t] = tmp
+    return out, co.to_limbs([(pool_k[a] + pool_k[b]) % pr.R for a, b in zip(ia, ib)])
 
 
 def rand_g2_limbs(rng, n):
