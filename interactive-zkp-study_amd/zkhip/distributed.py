@@ -83,15 +83,15 @@ def sharded_msm(group_id, local_partial, device=None, group=None):
 # n = n1 * n2 points, index j = j1 * n2 + j2 in, k = k1 + n1 * k2 out:
 #     X[k1 + n1 k2] = sum_j2 w_n2^(j2 k2) * [ w_n^(j2 k1) * sum_j1 x[j1 n2 + j2] w_n1^(j1 k1) ]
 # Layout "block-cyclic BC(m)": rank r owns the elements whose index i satisfies (i mod m) in [r m/R, (r+1) m/R),
-# stored as the row-major matrix [i div m][(i mod m) - r m/R].  The forward transform takes BC(n2) and leaves
-# BC(n1) (the same layout when n1 == n2, i.e. for even log n); the inverse takes BC(n1) back to BC(n2).  Pointwise
-# work between a forward and an inverse transform (the quotient of a prover) is layout-agnostic, and an MSM over
-# BC-distributed scalars only needs its points distributed the same way.
-#   1. local: n2/R column transforms of length n1 (transpose, zk_ntt_dev_batch)
+# stored residue-major as the matrix [(i mod m) - r m/R][i div m] (each owned residue class is one contiguous row).  The
+# forward transform takes BC(n2) and leaves BC(n1) (the same layout when n1 == n2, i.e. for even log n); the inverse
+# takes BC(n1) back to BC(n2).  Pointwise work between a forward and an inverse transform (the quotient of a prover)
+# is layout-agnostic, and an MSM over BC-distributed scalars only needs its points distributed the same way.
+#   1. local: the n2/R owned columns are contiguous rows -> n2/R transforms of length n1 in place (zk_ntt_dev_batch)
 #   2. local: twiddle w_n^(j2 k1)                                  (zk_ntt_twiddle_dev)
-#   3. ONE all-to-all: rank r sends rank s the k1-block of s of its columns (n/R^2 elements per pair; every
-#      pair of GPUs has its own xGMI link, so all links carry traffic at once)
-#   4. local: n1/R row transforms of length n2 (zk_ntt_dev_batch), transpose to [k2][k1 local]
+#   3. pack per destination, then ONE all-to-all: rank r sends rank s the k1-block of s of its columns (n/R^2
+#      elements per pair; every pair of GPUs has its own xGMI link, so all links carry traffic at once)
+#   4. local: transpose to [k1 local][j2], n1/R transforms of length n2 in place -- already the BC(n1) storage
 class _HipLocal:
     """The local kernels of DistNtt on this process's GPU."""
 
@@ -137,17 +137,17 @@ class DistNtt:
 
     # layouts ------------------------------------------------------------------------------------
     def local_shape_in(self):
-        return (self.n1, self.c)      # BC(n2): [j1][j2 local]
+        return (self.c, self.n1)      # BC(n2): [j2 local][j1]
 
     def local_shape_out(self):
-        return (self.n2, self.k)      # BC(n1): [k2][k1 local]
+        return (self.k, self.n2)      # BC(n1): [k1 local][k2]
 
     def scatter_in(self, full):
-        """Natural-order array (n, 4) -> this rank's BC(n2) block (n1, c, 4) (test / setup helper)."""
-        return full.reshape(self.n1, self.n2, 4)[:, self.rank * self.c:(self.rank + 1) * self.c].copy()
+        """Natural-order array (n, 4) -> this rank's BC(n2) block (c, n1, 4) (test / setup helper)."""
+        return np.ascontiguousarray(full.reshape(self.n1, self.n2, 4)[:, self.rank * self.c:(self.rank + 1) * self.c].transpose(1, 0, 2))
 
     def scatter_out(self, full):
-        return full.reshape(self.n2, self.n1, 4)[:, self.rank * self.k:(self.rank + 1) * self.k].copy()
+        return np.ascontiguousarray(full.reshape(self.n2, self.n1, 4)[:, self.rank * self.k:(self.rank + 1) * self.k].transpose(1, 0, 2))
 
     # transforms ---------------------------------------------------------------------------------
     def _exchange(self, send):
@@ -166,25 +166,25 @@ class DistNtt:
         return recv
 
     def forward(self, x):
-        """x: (n1, c, 4) int64 tensor, this rank's BC(n2) block -> (n2, k, 4), its BC(n1) block of the transform."""
+        """x: (c, n1, 4) int64 tensor, this rank's BC(n2) block (transformed in place as scratch) -> (k, n2, 4), its
+        BC(n1) block of the transform."""
         R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
-        cols = x.permute(1, 0, 2).contiguous()                        # [c][j1]
-        self.local.ntt_rows(cols, 1, False)                           # [c][k1]
-        self.local.twiddle(cols, self.rank * c, False)                # * w_n^(j2 k1), j2 = rank*c + c_local
-        send = cols.view(c, R, k, 4).permute(1, 0, 2, 3).contiguous()  # [s][c][k1 local of s]
+        self.local.ntt_rows(x, 1, False)                              # [c][j1] -> [c][k1]
+        self.local.twiddle(x, self.rank * c, False)                   # * w_n^(j2 k1), j2 = rank*c + c_local
+        send = x.view(c, R, k, 4).permute(1, 0, 2, 3).contiguous()    # [s][c][k1 local of s]
         recv = self._exchange(send)                                   # [r][c][k1 local]  ==  [j2][k1 local]
         rows = recv.view(n2, k, 4).permute(1, 0, 2).contiguous()      # [k1 local][j2]
         self.local.ntt_rows(rows, 2, False)                           # [k1 local][k2]
-        return rows.permute(1, 0, 2).contiguous()                     # [k2][k1 local]
+        return rows
 
     def inverse(self, y):
-        """y: (n2, k, 4), a BC(n1) block -> (n1, c, 4), the BC(n2) block of the inverse transform (1/n included)."""
+        """y: (k, n2, 4), a BC(n1) block (used as scratch) -> (c, n1, 4), the BC(n2) block of the inverse transform
+        (1/n included)."""
         R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
-        rows = y.permute(1, 0, 2).contiguous()                        # [k1 local][k2]
-        self.local.ntt_rows(rows, 2, True)                            # [k1 local][j2]   (1/n2 applied)
-        send = rows.view(k, R, c, 4).permute(1, 2, 0, 3).contiguous()  # [s][c local of s][k1 local]
+        self.local.ntt_rows(y, 2, True)                               # [k1 local][k2] -> [k1 local][j2]   (1/n2 applied)
+        send = y.view(k, R, c, 4).permute(1, 2, 0, 3).contiguous()    # [s][c local of s][k1 local]
         recv = self._exchange(send)                                   # [r][c][k1 local of r]
         cols = recv.permute(1, 0, 2, 3).contiguous().view(c, n1, 4)   # [c][k1]
         self.local.twiddle(cols, self.rank * c, True)                 # * w_n^(-j2 k1)
         self.local.ntt_rows(cols, 1, True)                            # [c][j1]          (1/n1 applied)
-        return cols.permute(1, 0, 2).contiguous()                     # [j1][c]
+        return cols

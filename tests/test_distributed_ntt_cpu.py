@@ -82,6 +82,6 @@ def test_dist_ntt_rejects_bad_world():
     sys.path.insert(0, os.path.join(HERE, "..", "interactive-zkp-study_amd"))
     from zkhip.distributed import DistNtt
     d = DistNtt(4, local=object())           # no process group: world 1
-    assert (d.world, d.n1, d.n2, d.c, d.k) == (1, 4, 4, 4, 4)
+    assert (d.world, d.n1, d.n2, d.c, d.k) == (1, 4, 4, 4, 4) and d.local_shape_in() == (4, 4)
     with pytest.raises(ValueError):
         DistNtt(4, l1=5, local=object())
