@@ -23,6 +23,7 @@
  * (8 limbs), G2 affine = x.c0||x.c1||y.c0||y.c1 (16 limbs); infinity = all-zero coordinates.
  */
 #include <stdint.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -389,6 +390,72 @@ int orc_g1_msm_bucket(const uint64_t *scalars, const uint64_t *points, size_t n,
     free(buckets);
     free(pts);
     return 0;
+}
+
+/* The same bucket method with the windows spread over `threads` POSIX threads (windows are independent; the window sums
+ * are combined by one Horner pass) -- bench.py's "all the cores a one-GPU box gives us" CPU line. */
+typedef struct {
+    const uint64_t *scalars;
+    const g1_jac *pts;
+    size_t n;
+    unsigned c, windows, first, stride;
+    g1_jac *wsum;
+    int rc;
+} msm_mt_job;
+static void *msm_mt_worker(void *arg) {
+    msm_mt_job *J = (msm_mt_job *)arg;
+    const size_t nb = ((size_t)1 << J->c) - 1;
+    g1_jac *buckets = (g1_jac *)malloc(sizeof(g1_jac) * nb);
+    if (!buckets) { J->rc = -2; return NULL; }
+    for (unsigned w = J->first; w < J->windows; w += J->stride) {
+        g1_jac run, wsum;
+        memset(buckets, 0, sizeof(g1_jac) * nb);
+        for (size_t i = 0; i < J->n; i++) {
+            unsigned d = window_digit(J->scalars + 4 * i, w * J->c, J->c);
+            if (d) g1_add(&buckets[d - 1], &buckets[d - 1], &J->pts[i]);
+        }
+        memset(&run, 0, sizeof(run));
+        memset(&wsum, 0, sizeof(wsum));
+        for (size_t b = nb; b-- > 0;) {
+            g1_add(&run, &run, &buckets[b]);
+            g1_add(&wsum, &wsum, &run);
+        }
+        J->wsum[w] = wsum;
+    }
+    free(buckets);
+    return NULL;
+}
+int orc_g1_msm_bucket_mt(const uint64_t *scalars, const uint64_t *points, size_t n, unsigned c, unsigned threads, uint64_t out[8]) {
+    ensure_init();
+    if (c < 1 || c > 20 || threads < 1 || threads > 64) return -1;
+    const unsigned windows = (254 + c - 1) / c;
+    if (threads > windows) threads = windows;
+    g1_jac *pts = (g1_jac *)malloc(sizeof(g1_jac) * (n ? n : 1));
+    g1_jac *wsum = (g1_jac *)calloc(windows, sizeof(g1_jac));
+    if (!pts || !wsum) { free(pts); free(wsum); return -2; }
+    for (size_t i = 0; i < n; i++) g1_load(&pts[i], points + 8 * i);
+    pthread_t tid[64];
+    msm_mt_job jobs[64];
+    int rc = 0;
+    for (unsigned t = 0; t < threads; t++) {
+        msm_mt_job j = {scalars, pts, n, c, windows, t, threads, wsum, 0};
+        jobs[t] = j;
+        if (pthread_create(&tid[t], NULL, msm_mt_worker, &jobs[t])) { jobs[t].rc = -3; msm_mt_worker(&jobs[t]); tid[t] = 0; }
+    }
+    for (unsigned t = 0; t < threads; t++) {
+        if (tid[t]) pthread_join(tid[t], NULL);
+        if (jobs[t].rc && jobs[t].rc != -3) rc = jobs[t].rc;
+    }
+    g1_jac total;
+    memset(&total, 0, sizeof(total));
+    for (int w = (int)windows - 1; w >= 0; w--) {
+        for (unsigned d = 0; d < c; d++) g1_dbl(&total, &total);
+        g1_add(&total, &total, &wsum[w]);
+    }
+    g1_store(out, &total);
+    free(pts);
+    free(wsum);
+    return rc;
 }
 
 /* Fixed-base batch: out[i] = k_i * P  (SRS.generate zkp/plonk/srs.py:77-82, sigma12 setup.py:18-23) */

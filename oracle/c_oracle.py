@@ -126,6 +126,17 @@ def g1_msm_bucket_arr(scalars, points, c=12):
     return O
 
 
+def g1_msm_bucket_mt_arr(scalars, points, c=13, threads=8):
+    """orc_g1_msm_bucket_mt: the bucket method with its windows spread over `threads` threads."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    O = np.zeros(8, dtype=np.uint64)
+    rc = lib().orc_g1_msm_bucket_mt(_p(scalars), _p(points), ctypes.c_size_t(scalars.shape[0]), ctypes.c_uint(c), ctypes.c_uint(threads), _p(O))
+    if rc:
+        raise RuntimeError("orc_g1_msm_bucket_mt failed: %d" % rc)
+    return O
+
+
 def g2_msm_arr(scalars, points):
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
     points = np.ascontiguousarray(points, dtype=np.uint64)

@@ -230,3 +230,5 @@ def test_c_oracle_bucket_msm_matches_naive():
     for c in (1, 4, 11, 16):
         assert (co.g1_msm_bucket_arr(S, P, c) == want).all()
     assert (co.g1_msm_bucket_arr(S[:0], P[:0], 8) == 0).all()
+    for threads in (1, 3, 64):
+        assert (co.g1_msm_bucket_mt_arr(S, P, 7, threads) == want).all()   # windows spread over threads
