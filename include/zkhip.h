@@ -145,6 +145,29 @@ int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals,
                    size_t rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * F_r vector primitives on DEVICE buffers of canonical elements -- what the coefficient / evaluation algebra of
+ * a prover is made of once its vectors live in HBM.  They replace, element-wise and without host round trips,
+ * Polynomial.__add__ / __sub__ / scale / evaluate (zkp/plonk/polynomial.py:85-162,189-198), poly_div by a linear
+ * factor (polynomial.py:385-436) and the grand product compute_accumulator (zkp/plonk/permutation.py:89-140):
+ *   zk_fr_lincomb_dev       out[i] = constant + sum_{j<k} coeffs[j] * in[j][i]     (k <= 8; coeffs, constant: HOST)
+ *   zk_fr_mul_dev           out[i] = a[i] * b[i]
+ *   zk_fr_scale_powers_dev  data[i] *= base^i            (evaluate(z) = sum of the scaled vector; coset shifts)
+ *   zk_fr_scan_dev          in-place inclusive scan, op 0: running sums, op 1: running products; reverse != 0 scans
+ *                           from the last element down (suffix sums / products).  Synthetic division by (x - z):
+ *                           q[i] = z^-(i+1) * sum_{j>i} c[j] z^j;  grand product: prefix products of the numerators
+ *                           times suffix products of the denominators over their total.
+ * A zk_frvec holds the scratch of the last two (power tables, per-level chunk totals); one per thread of use.
+ */
+typedef struct zk_frvec zk_frvec;
+int zk_frvec_create(zk_frvec **ws);
+int zk_frvec_destroy(zk_frvec *ws);
+int zk_fr_lincomb_dev(void *d_out, const void *const *d_in /* k HOST-side array of device pointers */, const uint64_t *coeffs /* k*4 */,
+                      unsigned k, const uint64_t constant[4] /* nullable */, size_t n, void *stream);
+int zk_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n, void *stream);
+int zk_fr_scale_powers_dev(zk_frvec *ws, void *d_data, size_t n, const uint64_t base[4], void *stream);
+int zk_fr_scan_dev(zk_frvec *ws, void *d_data, size_t n, int op, int reverse, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fixed-base batch scalar multiplication out[i] = scalars[i] * base  (HOST buffers).
  * Replaces the setup-side loops zkp/groth16/setup.py:18-23,56-60,65-69 and
  * zkp/plonk/srs.py:77-85 (one bn128.multiply(G, k_i) per element).

@@ -7,6 +7,7 @@
 #include "host_field.h"
 #include "msm.h"
 #include "ntt.h"
+#include "frvec.h"
 
 namespace zk {
 
@@ -253,6 +254,9 @@ struct zk_msm_plan {
 struct zk_ntt_plan {
     std::unique_ptr<NttPlan> impl;
 };
+struct zk_frvec {
+    FrVecScratch impl;
+};
 
 extern "C" {
 
@@ -466,6 +470,53 @@ int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals,
     return guarded([&] {
         if (rows && (!d_row_ptr || !d_col || !d_vals || !d_x || !d_y)) return invalid("zk_fr_spmv_dev: null pointer");
         fr_spmv(d_row_ptr, d_col, d_vals, d_x, d_y, rows, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_fr_lincomb_dev(void *d_out, const void *const *d_in, const uint64_t *coeffs, unsigned k, const uint64_t constant[4], size_t n, void *stream) {
+    return guarded([&] {
+        if (n && (!d_out || (k && (!d_in || !coeffs)))) return invalid("zk_fr_lincomb_dev: null pointer");
+        if (k > FR_LINCOMB_MAX) return invalid("zk_fr_lincomb_dev: at most 8 input vectors");
+        for (unsigned j = 0; j < k; j++)
+            if (!scalars_canonical(coeffs + 4 * j, 1)) return invalid("zk_fr_lincomb_dev: coefficient not canonical (>= r)");
+        if (constant && !scalars_canonical(constant, 1)) return invalid("zk_fr_lincomb_dev: constant not canonical (>= r)");
+        fr_lincomb(d_out, d_in, coeffs, k, constant, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n, void *stream) {
+    return guarded([&] {
+        if (n && (!d_out || !d_a || !d_b)) return invalid("zk_fr_mul_dev: null pointer");
+        fr_mul(d_out, d_a, d_b, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_frvec_create(zk_frvec **ws) {
+    return guarded([&] {
+        if (!ws) return invalid("zk_frvec_create: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        *ws = new zk_frvec;
+        return ZK_OK;
+    });
+}
+int zk_frvec_destroy(zk_frvec *ws) {
+    delete ws;
+    return ZK_OK;
+}
+int zk_fr_scale_powers_dev(zk_frvec *ws, void *d_data, size_t n, const uint64_t base[4], void *stream) {
+    return guarded([&] {
+        if (!ws || !base || (n && !d_data)) return invalid("zk_fr_scale_powers_dev: null pointer");
+        if (!scalars_canonical(base, 1)) return invalid("zk_fr_scale_powers_dev: base not canonical (>= r)");
+        ws->impl.scale_powers(d_data, n, base, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_fr_scan_dev(zk_frvec *ws, void *d_data, size_t n, int op, int reverse, void *stream) {
+    return guarded([&] {
+        if (!ws || (n && !d_data)) return invalid("zk_fr_scan_dev: null pointer");
+        if (op != 0 && op != 1) return invalid("zk_fr_scan_dev: op must be 0 (sum) or 1 (product)");
+        ws->impl.scan(d_data, n, op == 1, reverse != 0, (hipStream_t)stream);
         return ZK_OK;
     });
 }

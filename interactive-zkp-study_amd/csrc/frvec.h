@@ -1,0 +1,26 @@
+// frvec.h -- internal interface of the F_r vector primitives (frvec.hip).
+#pragma once
+#include <stdexcept>
+#include "common.h"
+#include "field.h"
+
+namespace zk {
+
+constexpr unsigned FR_LINCOMB_MAX = 8;
+
+// out[i] = constant + sum_{j<k} coeffs[j] * in[j][i]   (coeffs: k*4 HOST limbs; constant: HOST pointer or null)
+void fr_lincomb(void *d_out, const void *const *d_in, const uint64_t *coeffs, unsigned k, const uint64_t constant[4], size_t n, hipStream_t st);
+// out[i] = a[i] * b[i]
+void fr_mul(void *d_out, const void *d_a, const void *d_b, size_t n, hipStream_t st);
+
+// Scratch owned by whoever issues the calls (one per thread of use): power tables and the scan's per-level chunk totals.
+struct FrVecScratch {
+    DevBuf tables;
+    DevBuf levels[4];  // n <= 2^28: 2^17, 2^6 and 1 chunk totals
+    // x[i] *= base^i
+    void scale_powers(void *d_data, size_t n, const uint64_t base[4], hipStream_t st);
+    // in-place inclusive scan under + (mul == false) or * (mul == true); reverse: from the last element down
+    void scan(void *d_data, size_t n, bool mul, bool reverse, hipStream_t st);
+};
+
+}  // namespace zk

@@ -1,0 +1,244 @@
+// frvec.hip -- F_r vector primitives on device buffers of canonical elements (32 B each): linear combinations,
+// products, x[i] *= g^i, and inclusive scans under + or * in either direction.  They are what the coefficient /
+// evaluation algebra of a prover is made of once its vectors live in HBM: the reference's Polynomial.__add__ / scale /
+// __mul__ / evaluate (zkp/plonk/polynomial.py:85-162,189-198), poly_div by a linear factor (polynomial.py:385-436: synthetic
+// division = a suffix sum of c_j zeta^j) and the permutation grand product (zkp/plonk/permutation.py:89-140: prefix and
+// suffix products).  Used by zkhip/plonk/prover_device.py.
+#include <vector>
+#include <string.h>
+#include "frvec.h"
+#include "host_field.h"
+
+namespace zk {
+
+namespace {
+
+__device__ __forceinline__ Fr ldc(const uint32_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = q[0], b = q[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fe_from_words<FrTag>(w);
+}
+__device__ __forceinline__ void stc(uint32_t *p, const Fr &v) {
+    uint32_t w[8];
+    fe_to_words(fe_reduce_full(v), w);
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+struct LincombArgs {
+    const uint32_t *in[FR_LINCOMB_MAX];
+    Fr coef[FR_LINCOMB_MAX];  // Montgomery form: mont_mul(x, c * R) = x * c
+    Fr constant;              // plain value (< r), added to every element
+    uint32_t k;
+};
+
+// out[i] = constant + sum_j coef[j] * in[j][i]
+__global__ __launch_bounds__(256) void fr_lincomb_kernel(uint32_t *__restrict__ out, LincombArgs A, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = A.constant;
+    for (uint32_t j = 0; j < A.k; j++) {
+        acc = fe_add(acc, fe_mul(ldc(A.in[j] + i * 8), A.coef[j]));  // < 2r + 2r
+        fe_wreduce<4>(acc);                                           // < 2r
+    }
+    stc(out + i * 8, acc);
+}
+
+// out[i] = a[i] * b[i]
+__global__ __launch_bounds__(256) void fr_mul_kernel(uint32_t *__restrict__ out, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    stc(out + i * 8, fe_to_mont(fe_mul(ldc(a + i * 8), ldc(b + i * 8))));  // (ab / R) * R^2 / R = ab
+}
+
+// x[i] *= g^i with g^i = A[i & mask] * B[i >> lh] (two-level table, Montgomery form)
+__global__ __launch_bounds__(256) void fr_powers_kernel(uint32_t *__restrict__ x, const Fr *__restrict__ A, const Fr *__restrict__ B, uint32_t lh, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Fr w = fe_mul(A[i & (((size_t)1 << lh) - 1)], B[i >> lh]);
+    stc(x + i * 8, fe_mul(ldc(x + i * 8), w));
+}
+
+// ------------------------------------------------------------------------------ scans
+// Values are kept in the form in which `op` is one field operation: plain for +, Montgomery for * (mont_mul of two
+// Montgomery values is the Montgomery product).  Bounds: op results < 2r for both.
+template <bool MUL> __device__ __forceinline__ Fr scan_op(const Fr &a, const Fr &b) {
+    if (MUL) return fe_mul(a, b);
+    Fr s = fe_add(a, b);
+    fe_wreduce<4>(s);
+    return s;
+}
+template <bool MUL> __device__ __forceinline__ Fr scan_identity() { return MUL ? Fr::one() : Fr::zero(); }
+
+constexpr int SCAN_NT = 256, SCAN_EPT = 8, SCAN_CHUNK = SCAN_NT * SCAN_EPT;
+
+// Phase 1: every workgroup scans its 2048-element chunk in place (thread-serial over 8 consecutive elements, then a
+// Hillis-Steele pass over the 256 thread totals in LDS) and writes the chunk total.  REV scans from the end: logical
+// element e of the scan is physical element n - 1 - e.
+template <bool MUL, bool REV>
+__global__ __launch_bounds__(SCAN_NT) void fr_scan_chunk_kernel(uint32_t *__restrict__ x, uint32_t *__restrict__ totals, size_t n) {
+    __shared__ uint32_t sh[2][NL][SCAN_NT];
+    const uint32_t t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)t * SCAN_EPT;
+    Fr v[SCAN_EPT];
+    Fr run = scan_identity<MUL>();
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; k++) {
+        const size_t e = base + k;
+        if (e < n) {
+            Fr a = ldc(x + (REV ? n - 1 - e : e) * 8);
+            if (MUL) a = fe_to_mont(a);
+            run = scan_op<MUL>(run, a);
+        }
+        v[k] = run;
+    }
+    // inclusive scan of the thread totals
+    int cur = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) sh[0][i][t] = run.l[i];
+    __syncthreads();
+    for (uint32_t d = 1; d < SCAN_NT; d <<= 1) {
+        Fr mine, other;
+#pragma unroll
+        for (int i = 0; i < NL; i++) mine.l[i] = sh[cur][i][t];
+        if (t >= d) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) other.l[i] = sh[cur][i][t - d];
+            mine = scan_op<MUL>(other, mine);
+        }
+#pragma unroll
+        for (int i = 0; i < NL; i++) sh[cur ^ 1][i][t] = mine.l[i];
+        cur ^= 1;
+        __syncthreads();
+    }
+    Fr before = scan_identity<MUL>();
+    if (t > 0) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) before.l[i] = sh[cur][i][t - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; k++) {
+        const size_t e = base + k;
+        if (e < n) {
+            Fr r = t > 0 ? scan_op<MUL>(before, v[k]) : v[k];
+            if (MUL) r = fe_from_mont(r);
+            stc(x + (REV ? n - 1 - e : e) * 8, r);
+        }
+    }
+    if (t == SCAN_NT - 1) {
+        Fr tot;
+#pragma unroll
+        for (int i = 0; i < NL; i++) tot.l[i] = sh[cur][i][t];
+        if (MUL) tot = fe_from_mont(tot);
+        stc(totals + (size_t)blockIdx.x * 8, tot);
+    }
+}
+// Phase 3: element of chunk b (b >= 1) op= inclusive scan of the chunk totals at b - 1.
+template <bool MUL, bool REV>
+__global__ __launch_bounds__(SCAN_NT) void fr_scan_apply_kernel(uint32_t *__restrict__ x, const uint32_t *__restrict__ totals_scanned, size_t n) {
+    const size_t e = (size_t)blockIdx.x * SCAN_NT + threadIdx.x + SCAN_CHUNK;  // chunk 0 needs nothing
+    if (e >= n) return;
+    const size_t b = e / SCAN_CHUNK;
+    Fr pre = ldc(totals_scanned + (b - 1) * 8);
+    uint32_t *p = x + (REV ? n - 1 - e : e) * 8;
+    if (MUL)
+        stc(p, fe_mul(fe_to_mont(pre), ldc(p)));  // (pre R)(v) / R = pre v
+    else
+        stc(p, scan_op<false>(pre, ldc(p)));
+}
+
+template <bool MUL, bool REV> void scan_impl(uint32_t *x, size_t n, hipStream_t st, DevBuf *scratch, size_t level) {
+    if (n <= 1) return;
+    const size_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (level >= 4) throw std::runtime_error("zk_fr_scan_dev: vector too long");
+    if (scratch[level].bytes < chunks * 32) {
+        ZK_HIP(hipStreamSynchronize(st));
+        scratch[level].alloc(chunks * 32);
+    }
+    uint32_t *totals = scratch[level].as<uint32_t>();
+    hipLaunchKernelGGL((fr_scan_chunk_kernel<MUL, REV>), dim3((unsigned)chunks), dim3(SCAN_NT), 0, st, x, totals, n);
+    if (chunks > 1) {
+        scan_impl<MUL, false>(totals, chunks, st, scratch, level + 1);  // the totals array is already in scan order
+        hipLaunchKernelGGL((fr_scan_apply_kernel<MUL, REV>), dim3((unsigned)((n - SCAN_CHUNK + SCAN_NT - 1) / SCAN_NT)), dim3(SCAN_NT), 0, st, x, totals, n);
+    }
+    ZK_HIP(hipGetLastError());
+}
+
+HFr host_fr(const uint64_t v[4]) {
+    HFr a;
+    memcpy(a.l, v, 32);
+    return a;
+}
+
+}  // namespace
+
+void fr_lincomb(void *d_out, const void *const *d_in, const uint64_t *coeffs, unsigned k, const uint64_t constant[4], size_t n, hipStream_t st) {
+    if (k > FR_LINCOMB_MAX) throw std::runtime_error("zk_fr_lincomb_dev: at most 8 input vectors");
+    if (n == 0) return;
+    LincombArgs A;
+    memset(&A, 0, sizeof(A));
+    A.k = k;
+    for (unsigned j = 0; j < k; j++) {
+        A.in[j] = static_cast<const uint32_t *>(d_in[j]);
+        A.coef[j] = fe_to_mont(host_fr(coeffs + 4 * j)).to_dev();
+    }
+    if (constant) {
+        uint32_t w[8];
+        memcpy(w, constant, 32);
+        A.constant = fe_from_words<FrTag>(w);  // plain value, normalised limbs
+    } else {
+        A.constant = Fr::zero();
+    }
+    hipLaunchKernelGGL(fr_lincomb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out), A, n);
+    ZK_HIP(hipGetLastError());
+}
+
+void fr_mul(void *d_out, const void *d_a, const void *d_b, size_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fr_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out), static_cast<const uint32_t *>(d_a),
+                       static_cast<const uint32_t *>(d_b), n);
+    ZK_HIP(hipGetLastError());
+}
+
+void FrVecScratch::scale_powers(void *d_data, size_t n, const uint64_t base[4], hipStream_t st) {
+    if (n == 0) return;
+    unsigned L = 0;
+    while (((size_t)1 << L) < n) L++;
+    const unsigned lh = (L + 1) / 2;
+    const size_t na = (size_t)1 << lh, nb = ((n - 1) >> lh) + 1;
+    std::vector<Fr> h(na + nb);
+    const HFr g = fe_to_mont(host_fr(base));
+    HFr cur = HFr::one();
+    for (size_t i = 0; i < na; i++) {
+        h[i] = cur.to_dev();
+        cur = fe_mul(cur, g);
+    }
+    const HFr gh = cur;  // g^(2^lh)
+    cur = HFr::one();
+    for (size_t i = 0; i < nb; i++) {
+        h[na + i] = cur.to_dev();
+        cur = fe_mul(cur, gh);
+    }
+    // the table buffer may still be read by an earlier call on this stream: order the upload behind it
+    ZK_HIP(hipStreamSynchronize(st));
+    if (tables.bytes < h.size() * sizeof(Fr)) tables.alloc(h.size() * sizeof(Fr));
+    ZK_HIP(hipMemcpy(tables.p, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_data), tables.as<Fr>(),
+                       tables.as<Fr>() + na, lh, n);
+    ZK_HIP(hipGetLastError());
+}
+
+void FrVecScratch::scan(void *d_data, size_t n, bool mul, bool reverse, hipStream_t st) {
+    uint32_t *x = static_cast<uint32_t *>(d_data);
+    if (mul) {
+        if (reverse) scan_impl<true, true>(x, n, st, levels, 0);
+        else scan_impl<true, false>(x, n, st, levels, 0);
+    } else {
+        if (reverse) scan_impl<false, true>(x, n, st, levels, 0);
+        else scan_impl<false, false>(x, n, st, levels, 0);
+    }
+}
+
+}  // namespace zk

@@ -130,3 +130,45 @@ def fr_quotient(d_out, d_a, d_b, d_c, zinv, n, stream=0):
 def fr_spmv(d_row_ptr, d_col, d_vals, d_x, d_y, rows, stream=0):
     """y = M x over F_r, M in CSR form on device buffers (zk_fr_spmv_dev)."""
     _lib.check(_lib.load().zk_fr_spmv_dev(d_row_ptr, d_col, d_vals, d_x, d_y, rows, stream))
+
+
+class FrVec:
+    """F_r vector primitives on device buffers (zk_fr_lincomb_dev / _mul_dev / _scale_powers_dev / _scan_dev).
+    Arguments are raw device pointers to canonical elements (e.g. torch.Tensor.data_ptr() of an (n, 4) int64 tensor)."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().zk_frvec_create(ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.load().zk_frvec_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def lincomb(d_out, d_ins, coeffs, n, constant=None, stream=0):
+        """out[i] = constant + sum_j coeffs[j] * ins[j][i]  (at most 8 inputs; out may alias an input)."""
+        k = len(d_ins)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[ctypes.c_void_p(int(p)) for p in d_ins])
+        cf = _lib.ints_to_limbs([int(c) for c in coeffs]) if k else np.zeros((1, 4), dtype=np.uint64)
+        cst = None if constant is None else _lib.ints_to_limbs([int(constant)])
+        _lib.check(_lib.load().zk_fr_lincomb_dev(d_out, ptrs, _lib.ptr(cf), k, None if cst is None else _lib.ptr(cst), n, stream))
+
+    @staticmethod
+    def mul(d_out, d_a, d_b, n, stream=0):
+        _lib.check(_lib.load().zk_fr_mul_dev(d_out, d_a, d_b, n, stream))
+
+    def scale_powers(self, d_data, n, base, stream=0):
+        """data[i] *= base^i."""
+        b = _lib.ints_to_limbs([int(base)])
+        _lib.check(_lib.load().zk_fr_scale_powers_dev(self._h, d_data, n, _lib.ptr(b), stream))
+
+    def scan(self, d_data, n, product=False, reverse=False, stream=0):
+        """In-place inclusive scan: running sums (product=False) or products; reverse: from the last element down."""
+        _lib.check(_lib.load().zk_fr_scan_dev(self._h, d_data, n, 1 if product else 0, 1 if reverse else 0, stream))
