@@ -1,0 +1,284 @@
+"""PLONK preprocessing and prover with every vector resident in HBM (SURVEY.md section 8 row f3 at scale).
+
+Same protocol, transcript, blinding degrees and proof fields as zkhip/plonk/prover.py (which mirrors
+zkp/plonk/prover/round1..5.py on Python lists and is what the reference-sized circuits use); here the columns,
+selector / permutation polynomials and the SRS are device buffers and the rounds are sequences of backend calls:
+
+  interpolation, coset evaluation      zk_ntt_dev (NttPlan)
+  commitments                          zk_msm_submit / collect (MsmPlan, up to three in flight)
+  a + beta*id + gamma, gate terms ...  zk_fr_lincomb_dev, zk_fr_mul_dev
+  grand product z                      prefix products of the numerators, suffix products of the denominators (zk_fr_scan_dev)
+  p(zeta)                              zk_fr_scale_powers_dev + running sum
+  (p(x) - p(z)) / (x - z)              q[i] = z^-(i+1) * sum_{j>i} c[j] z^j: scale, suffix sums, scale
+
+The host only hashes the transcript and handles the ~20 scalars between rounds.  With the same blinding scalars the
+proof equals the list prover's bit for bit (tests/test_gpu_plonk_device.py); the reference's quirks (PI(x) = 0, no
+blinding of t) are kept."""
+import secrets
+
+import numpy as np
+
+from .. import _lib
+from ..device import FrVec, MsmPlan, NttPlan
+from ..field import FR, CURVE_ORDER as R, get_root_of_unity, limbs_to_g1
+from .permutation import K1, K2
+from .prover import COSET_K, Proof, linearisation_scalars
+from .transcript import Transcript
+
+PAD = 8  # slack coefficients behind the n of every polynomial buffer (blinding adds up to 3, t_hi up to 6)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dev(limbs):
+    return _torch().from_numpy(np.ascontiguousarray(limbs).view(np.int64)).cuda()
+
+
+def _limbs(ints):
+    return _lib.ints_to_limbs([int(v) % R for v in ints])
+
+
+class DevicePlonk:
+    """Circuit of n = 2^k gates given by its selector and permutation EVALUATIONS on the domain (limb arrays
+    (n, 4) uint64: q_l, q_r, q_o, q_m, q_c, s_sigma1..3) and an SRS as a limb array of G1 points (>= n + 6 rows)."""
+
+    def __init__(self, selectors, sigmas, srs_g1_limbs):
+        torch = _torch()
+        n = selectors[0].shape[0]
+        if n < 4 or n & (n - 1):
+            raise ValueError("DevicePlonk: n must be a power of two >= 4")
+        if srs_g1_limbs.shape[0] < n + 6:
+            raise ValueError("DevicePlonk: the SRS must hold at least n + 6 powers")
+        self.n, self.log_n = n, n.bit_length() - 1
+        self.omega = get_root_of_unity(n)
+        self.size = 1
+        while self.size < 3 * n + 6:
+            self.size <<= 1
+        self.step = self.size // n
+        self.st = torch.cuda.current_stream().cuda_stream
+        self.fv = FrVec()
+        self.ntt_n = NttPlan(self.log_n)
+        self.ntt_big = NttPlan(self.size.bit_length() - 1)
+        self.msm = MsmPlan(_lib.GROUP_G1, n + PAD)
+        self.srs = _dev(srs_g1_limbs[:n + PAD] if srs_g1_limbs.shape[0] >= n + PAD else np.concatenate(
+            [srs_g1_limbs, np.zeros((n + PAD - srs_g1_limbs.shape[0], 8), dtype=np.uint64)]))
+        names = ("q_l", "q_r", "q_o", "q_m", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")
+        self.evals = {k: _dev(v) for k, v in zip(names, list(selectors) + list(sigmas))}
+        # coefficient forms (8 inverse NTTs) and commitments (8 MSMs)
+        self.coef, self.comm = {}, {}
+        for k in names:
+            self.coef[k] = self._interpolate(self.evals[k])
+        for k in names:
+            self.comm[k] = self._commit(self.coef[k], n)
+        # identity labels omega^i (times 1, K1, K2 by coefficient) and everything the quotient needs on the coset k*H'
+        ones = _dev(_limbs([1] * n))
+        self.fv.scale_powers(ones.data_ptr(), n, int(self.omega), self.st)
+        self.ident = ones
+        self.coset = {k: self._coset(self.coef[k]) for k in names}
+        x_coef = self._zeros(n + PAD)
+        x_coef[1:2] = _dev(_limbs([1]))
+        self.coset["x"] = self._coset(x_coef)
+        l1_coef = self._zeros(n + PAD)
+        l1_coef[:n] = _dev(_limbs([pow(n, -1, R)] * n))          # L_1(x) = (x^n - 1) / (n (x - 1)) = (1/n) sum_j x^j
+        self.coset["l1"] = self._coset(l1_coef)
+        w_big = int(get_root_of_unity(self.size))
+        zh_inv = [pow((pow(COSET_K * pow(w_big, i, R) % R, n, R) - 1) % R, -1, R) for i in range(self.step)]
+        self.coset["zh_inv"] = _dev(_limbs(zh_inv)).repeat(self.size // self.step, 1).contiguous()  # x^n has period `step` on the coset
+
+    # ---- helpers -------------------------------------------------------------------------------------------
+    def _zeros(self, rows):
+        return _torch().zeros((rows, 4), dtype=_torch().int64, device="cuda")
+
+    def _interpolate(self, evals):
+        """(n, 4) evaluations on the domain -> zero-padded coefficient buffer (n + PAD, 4)."""
+        out = self._zeros(self.n + PAD)
+        out[:self.n] = evals
+        self.ntt_n.run(out.data_ptr(), True, None, self.st)
+        return out
+
+    def _coset(self, coef):
+        """Coefficient buffer -> evaluations on the coset k*H' (size, 4)."""
+        out = self._zeros(self.size)
+        m = min(coef.shape[0], self.size)
+        out[:m] = coef[:m]
+        self.ntt_big.run(out.data_ptr(), False, COSET_K, self.st)
+        return out
+
+    def _commit(self, coef, count):
+        limbs, inf = self.msm.run_limbs(coef.data_ptr(), self.srs.data_ptr(), count, self.st)
+        return None if inf else limbs_to_g1(limbs)[0]
+
+    def _commit_many(self, items):
+        """[(coef, count)] -> points; the MSMs are kept in flight together."""
+        depth, pend, out = self.msm.max_in_flight(), [], []
+        for coef, count in items:
+            if len(pend) == depth:
+                out.append(self.msm.collect_limbs(pend.pop(0)))
+            pend.append(self.msm.submit(coef.data_ptr(), self.srs.data_ptr(), count, self.st))
+        out += [self.msm.collect_limbs(t) for t in pend]
+        return [None if inf else limbs_to_g1(limbs)[0] for limbs, inf in out]
+
+    def _lin(self, out, ins, coeffs, n, constant=None):
+        FrVec.lincomb(out.data_ptr(), [t.data_ptr() for t in ins], coeffs, n, constant, self.st)
+
+    def _mul(self, out, a, b, n):
+        FrVec.mul(out.data_ptr(), a.data_ptr(), b.data_ptr(), n, self.st)
+
+    def _evaluate(self, coef, count, point):
+        """p(point) = sum_i c_i point^i (polynomial.py:85-106)."""
+        tmp = coef[:count].clone()
+        self.fv.scale_powers(tmp.data_ptr(), count, int(point), self.st)
+        self.fv.scan(tmp.data_ptr(), count, False, False, self.st)
+        return FR(_lib.limbs_to_ints(tmp[count - 1:count].cpu().numpy().view(np.uint64))[0])
+
+    def _divide_linear(self, coef, count, point):
+        """Quotient of p(x) / (x - point), count - 1 coefficients (the remainder p(point) is dropped)."""
+        tmp = coef[:count].clone()
+        z = int(point) % R
+        self.fv.scale_powers(tmp.data_ptr(), count, z, self.st)
+        self.fv.scan(tmp.data_ptr(), count, False, True, self.st)              # suffix sums of c_j z^j
+        q = self._zeros(self.n + PAD)
+        q[:count - 1] = tmp[1:count]
+        zi = pow(z, -1, R)
+        self.fv.scale_powers(q.data_ptr(), count - 1, zi, self.st)
+        self._lin(q, [q], [zi], count - 1)
+        return q
+
+    def _blinded(self, coef, blind):
+        """coef + blind(x) * (x^n - 1) in place (round1.py:92-108)."""
+        n, k = self.n, len(blind)
+        bl = _dev(_limbs(blind))
+        self._lin(coef[:k], [coef[:k], bl], [1, R - 1], k)
+        self._lin(coef[n:n + k], [coef[n:n + k], bl], [1, 1], k)
+        return coef
+
+    # ---- interface to the verifier ---------------------------------------------------------------------------
+    def preprocessed(self):
+        """Object with the fields zkhip.plonk.verifier.verify reads (preprocessor.py:59-130)."""
+        class PP:
+            pass
+        pp = PP()
+        pp.n, pp.omega = self.n, self.omega
+        for k, c in self.comm.items():
+            setattr(pp, k + "_comm", c)
+        return pp
+
+    # ---- the five rounds ---------------------------------------------------------------------------------------
+    def prove(self, a_vals, b_vals, c_vals, blinding=None):
+        """a_vals, b_vals, c_vals: (n, 4) limb arrays or device tensors of the wire columns -> Proof."""
+        torch = _torch()
+        n, size, step, fv, st = self.n, self.size, self.step, self.fv, self.st
+        blind = list(blinding) if blinding is not None else [secrets.randbelow(R) for _ in range(9)]
+        if len(blind) < 9:
+            raise ValueError("not enough blinding scalars supplied")
+        cols = [v if torch.is_tensor(v) else _dev(v) for v in (a_vals, b_vals, c_vals)]
+        tr, pr = Transcript(), Proof()
+        k1, k2 = int(K1), int(K2)
+
+        # round 1 (round1.py:55-108)
+        wires = [self._blinded(self._interpolate(col), blind[2 * i:2 * i + 2]) for i, col in enumerate(cols)]
+        for name, comm in zip(("a_comm", "b_comm", "c_comm"), self._commit_many([(w, n + 2) for w in wires])):
+            setattr(pr, name, comm)
+            tr.append_point(name.encode(), comm)
+
+        # round 2 (round2.py:50-86, permutation.py:89-137)
+        beta, gamma = tr.challenge_scalar(b"beta"), tr.challenge_scalar(b"gamma")
+        be, ga = int(beta), int(gamma)
+        num, den, tmp = self._zeros(n), self._zeros(n), self._zeros(n)
+        sig = [self.evals["s_sigma%d" % k] for k in (1, 2, 3)]
+        for j, (col, idc) in enumerate(zip(cols, (1, k1, k2))):
+            self._lin(tmp, [col, self.ident], [1, be * idc % R], n, ga)          # w + beta * k * omega^i + gamma
+            if j == 0:
+                num.copy_(tmp)
+            else:
+                self._mul(num, num, tmp, n)
+            self._lin(tmp, [col, sig[j]], [1, be], n, ga)                        # w + beta * sigma(i) + gamma
+            if j == 0:
+                den.copy_(tmp)
+            else:
+                self._mul(den, den, tmp, n)
+        fv.scan(num.data_ptr(), n, True, False, st)                              # prod_{j<=i} num_j
+        fv.scan(den.data_ptr(), n, True, True, st)                               # prod_{j>=i} den_j
+        den_total = _lib.limbs_to_ints(den[:1].cpu().numpy().view(np.uint64))[0]
+        z_ev = self._zeros(n)
+        z_ev[:1] = _dev(_limbs([1]))
+        self._mul(z_ev[1:], num[:n - 1], den[1:], n - 1)                         # z_i = prod_{j<i} num_j / den_j
+        self._lin(z_ev[1:], [z_ev[1:]], [pow(den_total, -1, R)], n - 1)
+        z = self._blinded(self._interpolate(z_ev), blind[6:9])
+        pr.z_comm = self._commit(z, n + 3)
+        tr.append_point(b"z_comm", pr.z_comm)
+
+        # round 3 (round3.py:80-187): t = (gate + alpha perm + alpha^2 (z - 1) L1) / Z_H on the coset
+        alpha = tr.challenge_scalar(b"alpha")
+        al = int(alpha)
+        cs = self.coset
+        ea, eb, ec, ez = (self._coset(p) for p in (wires[0], wires[1], wires[2], z))
+        ezw = torch.roll(ez, -step, 0)                                           # z(omega x): omega = w_big^step
+        tot, t1, t2 = self._zeros(size), self._zeros(size), self._zeros(size)
+        self._mul(t1, ea, eb, size)
+        self._mul(tot, t1, cs["q_m"], size)
+        for sel, ev in (("q_l", ea), ("q_r", eb), ("q_o", ec)):
+            self._mul(t1, cs[sel], ev, size)
+            self._lin(tot, [tot, t1], [1, 1], size)
+        self._lin(tot, [tot, cs["q_c"]], [1, 1], size)                           # + PI(x) = 0
+        for sign, other, z_side in ((1, [cs["x"], cs["x"], cs["x"]], ez), (R - 1, [cs["s_sigma1"], cs["s_sigma2"], cs["s_sigma3"]], ezw)):
+            for j, (ev, idc) in enumerate(zip((ea, eb, ec), (1, k1, k2))):
+                coef = be * (idc if sign == 1 else 1) % R
+                self._lin(t2, [ev, other[j]], [1, coef], size, ga)
+                if j == 0:
+                    t1.copy_(t2)
+                else:
+                    self._mul(t1, t1, t2, size)
+            self._mul(t1, t1, z_side, size)
+            self._lin(tot, [tot, t1], [1, al * sign % R], size)
+        self._lin(t1, [ez], [1], size, R - 1)                                    # z - 1
+        self._mul(t1, t1, cs["l1"], size)
+        self._lin(tot, [tot, t1], [1, al * al % R], size)
+        self._mul(tot, tot, cs["zh_inv"], size)
+        self.ntt_big.run(tot.data_ptr(), True, COSET_K, st)
+        if bool(tot[3 * n + 6:].any()):
+            raise ValueError("constraint polynomial is not divisible by Z_H: circuit or witness is inconsistent")
+        t_parts = []
+        for lo, hi in ((0, n), (n, 2 * n), (2 * n, 3 * n + 6)):
+            part = self._zeros(n + PAD)
+            part[:hi - lo] = tot[lo:hi]
+            t_parts.append(part)
+        for name, comm in zip(("t_lo_comm", "t_mid_comm", "t_hi_comm"), self._commit_many([(t_parts[0], n), (t_parts[1], n), (t_parts[2], n + 6)])):
+            setattr(pr, name, comm)
+            tr.append_point(name.encode(), comm)
+
+        # round 4 (round4.py:40-79)
+        zeta = tr.challenge_scalar(b"zeta")
+        pr.a_eval = self._evaluate(wires[0], n + 2, zeta)
+        pr.b_eval = self._evaluate(wires[1], n + 2, zeta)
+        pr.c_eval = self._evaluate(wires[2], n + 2, zeta)
+        pr.s_sigma1_eval = self._evaluate(self.coef["s_sigma1"], n, zeta)
+        pr.s_sigma2_eval = self._evaluate(self.coef["s_sigma2"], n, zeta)
+        pr.z_omega_eval = self._evaluate(z, n + 3, zeta * self.omega)
+        for name in ("a_eval", "b_eval", "c_eval", "s_sigma1_eval", "s_sigma2_eval", "z_omega_eval"):
+            tr.append_scalar(name.encode(), getattr(pr, name))
+
+        # round 5 (round5.py:78-177)
+        v = tr.challenge_scalar(b"v")
+        _, l1_zeta, perm_z, perm_s3, r0 = linearisation_scalars(alpha, beta, gamma, zeta, n, self.omega, pr.a_eval, pr.b_eval, pr.c_eval,
+                                                               pr.s_sigma1_eval, pr.s_sigma2_eval, pr.z_omega_eval)
+        cf = self.coef
+        r_poly = self._zeros(n + PAD)
+        self._lin(r_poly, [cf["q_m"], cf["q_l"], cf["q_r"], cf["q_o"], cf["q_c"], z, cf["s_sigma3"]],
+                  [int(pr.a_eval * pr.b_eval), int(pr.a_eval), int(pr.b_eval), int(pr.c_eval), 1, int(perm_z + alpha * alpha * l1_zeta), int(FR(0) - perm_s3)],
+                  n + PAD)
+        self._lin(r_poly[:1], [r_poly[:1]], [1], 1, int(r0))                     # + (PI(zeta) + r0), PI = 0
+        pr.r_eval = self._evaluate(r_poly, n + 3, zeta)
+        zeta_n = zeta ** n
+        numer = self._zeros(n + PAD)
+        vs = [int(v ** k) for k in range(1, 7)]
+        self._lin(numer, [t_parts[0], t_parts[1], t_parts[2], r_poly, wires[0], wires[1], wires[2], cf["s_sigma1"]],
+                  [1, int(zeta_n), int(zeta_n * zeta_n), vs[0], vs[1], vs[2], vs[3], vs[4]], n + PAD)
+        self._lin(numer, [numer, cf["s_sigma2"]], [1, vs[5]], n + PAD)
+        w_zeta = self._divide_linear(numer, n + 6, zeta)                         # the constant terms only change the dropped remainder
+        w_zeta_omega = self._divide_linear(z, n + 3, zeta * self.omega)
+        pr.W_zeta_comm, pr.W_zeta_omega_comm = self._commit_many([(w_zeta, n + 5), (w_zeta_omega, n + 2)])
+        return pr

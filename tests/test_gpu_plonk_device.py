@@ -1,0 +1,129 @@
+"""GPU tests of the device-resident PLONK prover (zkhip.plonk.prover_device.DevicePlonk, SURVEY.md section 8 row f3 at
+scale): with the same blinding scalars its proof and preprocessing commitments equal the list prover's (which mirrors
+zkp/plonk/prover/round1..5.py) bit for bit; proofs of a 2^12-gate synthetic circuit verify and tampered ones do not."""
+import copy
+
+import numpy as np
+import pytest
+
+import py_ref as o
+from zkhip import _lib
+from zkhip.field import FR, g1_to_limbs
+from zkhip.plonk.circuit import Circuit
+from zkhip.plonk.permutation import build_permutation_polynomials
+from zkhip.plonk.preprocessor import preprocess
+from zkhip.plonk.prover import Proof, prove
+from zkhip.plonk.prover_device import DevicePlonk
+from zkhip.plonk.srs import SRS
+from zkhip.plonk.verifier import verify
+
+pytestmark = pytest.mark.gpu
+R = o.R
+
+
+def _limbs(vals):
+    return _lib.ints_to_limbs([int(v) % R for v in vals])
+
+
+def _chain_circuit(rows, seed):
+    """Alternating multiplication / addition gates, each output wired to the next gate's left input."""
+    rng = np.random.default_rng(seed)
+    c = Circuit()
+    a, b, cc = [], [], []
+    cur = int(rng.integers(2, 1 << 40))
+    for i in range(rows):
+        y = int(rng.integers(1, 1 << 40))
+        if i % 2 == 0:
+            g = c.add_multiplication_gate()
+            out = cur * y % R
+        else:
+            g = c.add_addition_gate()
+            out = (cur + y) % R
+        a.append(FR(cur)); b.append(FR(y)); cc.append(FR(out))
+        if i:
+            c.add_copy_constraint(g - 1, 2, g, 0)
+        cur = out
+    return c, a, b, cc
+
+
+def _device_from_circuit(circuit, pp, srs):
+    sel = [_limbs(col) for col in circuit.get_selector_polynomials()]
+    sig = [_limbs(col) for col in build_permutation_polynomials(pp.sigma, pp.n, pp.domain)]
+    return DevicePlonk(sel, sig, g1_to_limbs(srs.g1_powers))
+
+
+@pytest.mark.parametrize("which", ["toy", "chain13", "chain64"])
+def test_device_prover_equals_list_prover(which):
+    if which == "toy":
+        circuit, a, b, c, pub = Circuit.x3_plus_x_plus_5_eq_35()     # n = 4: quotient domain 8n
+    else:
+        circuit, a, b, c = _chain_circuit(13 if which == "chain13" else 64, 5)
+        pub = []
+    srs = SRS.generate(len(circuit.gates) + 80, seed=42)
+    pp = preprocess(circuit, srs)                                    # pads the circuit to a power of two
+    n = pp.n
+    pad = lambda col: list(col) + [FR(0)] * (n - len(col))
+    a, b, c = pad(a), pad(b), pad(c)
+    blinding = [1000 + 7 * i for i in range(9)]
+    want = prove(circuit, a, b, c, pub, pp, srs, blinding=blinding)
+    dev = _device_from_circuit(circuit, pp, srs)
+    dpp = dev.preprocessed()
+    for name in ("q_l", "q_r", "q_o", "q_m", "q_c", "s_sigma1", "s_sigma2", "s_sigma3"):
+        assert getattr(dpp, name + "_comm") == getattr(pp, name + "_comm"), name
+    got = dev.prove(_limbs(a), _limbs(b), _limbs(c), blinding=blinding)
+    for f in Proof.FIELDS:
+        assert getattr(got, f) == getattr(want, f), f
+    assert verify(got, pub, dpp, srs)
+    fresh = dev.prove(_limbs(a), _limbs(b), _limbs(c))                # random blinding: a different, valid proof
+    assert fresh.a_comm != got.a_comm and verify(fresh, pub, dpp, srs)
+
+
+def test_device_prover_2pow12_verifies_and_rejects_tampering():
+    from zkhip.field import G1, G2, fixed_base_mul
+    rng = np.random.default_rng(77)
+    n = 1 << 12
+    # synthetic circuit straight as arrays: gate i multiplies (even i) or adds (odd i); c_i is wired to a_{i+1}
+    even = (np.arange(n) % 2 == 0)
+    q_m = even.astype(object)
+    q_l = (~even).astype(object)
+    q_r = (~even).astype(object)
+    q_o = np.array([R - 1] * n, dtype=object)
+    q_c = np.array([0] * n, dtype=object)
+    a, b, c = [0] * n, [0] * n, [0] * n
+    cur = 3
+    for i in range(n):
+        y = int(rng.integers(1, 1 << 50))
+        a[i], b[i] = cur, y
+        c[i] = cur * y % R if i % 2 == 0 else (cur + y) % R
+        cur = c[i]
+    sigma = list(range(3 * n))
+    for i in range(1, n):                                             # position = wire * n + gate
+        p1, p2 = 2 * n + (i - 1), i
+        sigma[p1], sigma[p2] = sigma[p2], sigma[p1]
+    w = pow(5, (R - 1) // n, R)
+    dom = [pow(w, i, R) for i in range(n)]
+    label = lambda pos: dom[pos] if pos < n else (2 * dom[pos - n] % R if pos < 2 * n else 3 * dom[pos - 2 * n] % R)
+    sig = [[label(sigma[col * n + i]) for i in range(n)] for col in range(3)]
+    tau = 0xC0FFEE1234567
+    powers, t = [], 1
+    for _ in range(n + 8):
+        powers.append(t)
+        t = t * tau % R
+    srs_limbs = g1_to_limbs(fixed_base_mul(G1, powers))
+
+    class Srs:                                                         # what the verifier reads
+        g2_powers = [G2] + fixed_base_mul(G2, [tau])
+    dev = DevicePlonk([_limbs(q) for q in (q_l, q_r, q_o, q_m, q_c)], [_limbs(s) for s in sig], srs_limbs)
+    proof = dev.prove(_limbs(a), _limbs(b), _limbs(c))
+    pp = dev.preprocessed()
+    assert verify(proof, [], pp, Srs)
+    bad = copy.copy(proof)
+    bad.a_eval = proof.a_eval + FR(1)
+    assert not verify(bad, [], pp, Srs)
+    bad = copy.copy(proof)
+    bad.t_mid_comm = proof.t_lo_comm
+    assert not verify(bad, [], pp, Srs)
+    c_bad = list(c)
+    c_bad[100] = (c_bad[100] + 1) % R                                   # unsatisfied gate: t is not a polynomial
+    with pytest.raises(ValueError):
+        dev.prove(_limbs(a), _limbs(b), _limbs(c_bad))
