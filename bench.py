@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 size of the secondary NTT measurement (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="points timed on the pure-Python baseline (0 = skip)")
     ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
+    ap.add_argument("--plonk-log-n", type=int, default=20, help="log2 gates of the secondary device-resident PLONK prove() timing (0 = skip)")
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
     args = ap.parse_args()
@@ -244,6 +245,15 @@ def main():
             extra["groth16_prove"] = bench_groth16.run(args.groth16_log_m, 6)
         except Exception as exc:  # the headline number must not depend on the secondary measurement
             extra["groth16_prove"] = {"error": repr(exc)}
+
+    # ---- secondary: PLONK prove() on a synthetic 2^20-gate circuit, all vectors resident in HBM
+    if args.plonk_log_n and world == 1:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_plonk
+            extra["plonk_prove"] = bench_plonk.run(args.plonk_log_n, 3)
+        except Exception as exc:
+            extra["plonk_prove"] = {"error": repr(exc)}
 
     # ---- CPU baseline: reference-shaped pure-Python path on a bounded sample (rank 0, N = 1 only)
     cpu = None

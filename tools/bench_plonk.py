@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""PLONK prove() wall-clock on a synthetic 2^log_n-gate circuit with everything resident in HBM
+(zkhip.plonk.prover_device.DevicePlonk): alternating multiplication / addition gates, each output wired to the next
+gate's left input.  The proof is checked by the verifier (two pairings on the host).
+    python tools/bench_plonk.py --log-n 20 --reps 3"""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
+
+
+def mulmod_limbs(vals):
+    from zkhip import _lib
+    return _lib.ints_to_limbs(vals)
+
+
+def run(log_n, reps):
+    import torch
+    from zkhip import _lib
+    from zkhip.field import CURVE_ORDER as R, G1, G2, fixed_base_mul, get_root_of_unity
+    from zkhip.plonk.prover_device import DevicePlonk
+    from zkhip.plonk.verifier import verify
+    n = 1 << log_n
+    rng = np.random.default_rng(11)
+    t0 = time.perf_counter()
+    ys = [int(v) for v in rng.integers(1, 1 << 50, size=n)]
+    a, c = [0] * n, [0] * n
+    cur = 3
+    for i in range(n):
+        a[i] = cur
+        cur = cur * ys[i] % R if i % 2 == 0 else (cur + ys[i]) % R
+        c[i] = cur
+    t_wit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lib = _lib.load()
+    col = lambda even_val, odd_val: _lib.ints_to_limbs([even_val, odd_val] * (n // 2))
+    sel = [col(0, 1), col(0, 1), col(R - 1, R - 1), col(1, 0), col(0, 0)]                # q_l, q_r, q_o, q_m, q_c
+    # labels: omega^i via one device batch k_i * 1 is overkill -- powers in Python are the setup cost here
+    w = int(get_root_of_unity(n))
+    dom, curw = [0] * n, 1
+    for i in range(n):
+        dom[i] = curw
+        curw = curw * w % R
+    # sigma: c_{i-1} <-> a_i swapped, everything else fixed
+    s1 = [dom[0]] + [3 * dom[i - 1] % R for i in range(1, n)]          # a_i  -> position of c_{i-1}
+    s2 = [2 * d % R for d in dom]                                        # b_i  -> itself
+    s3 = [dom[i + 1] for i in range(n - 1)] + [3 * dom[n - 1] % R]      # c_i  -> position of a_{i+1}
+    sig = [_lib.ints_to_limbs(s) for s in (s1, s2, s3)]
+    tau = 0xC0FFEE1234567
+    powers, t = [0] * (n + 8), 1
+    for i in range(n + 8):
+        powers[i] = t
+        t = t * tau % R
+    P = np.zeros((n + 8, 8), dtype=np.uint64)
+    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(powers)), n + 8, _lib.ptr(P)))
+    dev = DevicePlonk(sel, sig, P)
+    t_pre = time.perf_counter() - t0
+    cols = [torch.from_numpy(_lib.ints_to_limbs(v).view(np.int64)).cuda() for v in (a, ys, c)]
+    times = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proof = dev.prove(*cols)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+
+    class Srs:
+        g2_powers = [G2] + fixed_base_mul(G2, [tau])
+    ok = verify(proof, [], dev.preprocessed(), Srs)
+    return {"log_n": log_n, "gates": n, "prove_ms": round(min(times[1:]) * 1e3, 3), "prove_ms_all": [round(t * 1e3, 3) for t in times[1:]],
+            "first_call_ms": round(times[0] * 1e3, 3), "witness_gen_s_python": round(t_wit, 2), "preprocess_s": round(t_pre, 2), "verified": bool(ok)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    print(json.dumps(run(args.log_n, args.reps)), flush=True)
