@@ -158,6 +158,16 @@ int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals,
  *                           times suffix products of the denominators over their total.
  * A zk_frvec holds the scratch of the last two (power tables, per-level chunk totals); one per thread of use.
  */
+/* The PLONK round-3 quotient in one pass (zkp/plonk/prover/round3.py:114-147 builds the numerator by polynomial products and
+ * divides by Z_H with poly_div): for every point of the evaluation coset
+ *   out = (q_L a + q_R b + q_O c + q_M a b + q_C
+ *          + alpha [ (a + beta x + gamma)(b + 2 beta x + gamma)(c + 3 beta x + gamma) z
+ *                  - (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma) zw ]
+ *          + alpha^2 (z - 1) L1) * zh_inv[i mod period]
+ * d_in: 15 device vectors in the order a b c z zw | q_L q_R q_O q_M q_C | s1 s2 s3 | x L1 (zw = z at omega x);
+ * zh_inv: `period` (1, 2, 4 or 8) HOST elements, 1 / Z_H repeats with that period on the coset. */
+int zk_plonk_quotient_dev(void *d_out, const void *const *d_in, const uint64_t *zh_inv, unsigned period, const uint64_t alpha[4],
+                          const uint64_t beta[4], const uint64_t gamma[4], size_t n, void *stream);
 typedef struct zk_frvec zk_frvec;
 int zk_frvec_create(zk_frvec **ws);
 int zk_frvec_destroy(zk_frvec *ws);

@@ -491,6 +491,19 @@ int zk_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n, void 
         return ZK_OK;
     });
 }
+int zk_plonk_quotient_dev(void *d_out, const void *const *d_in, const uint64_t *zh_inv, unsigned period, const uint64_t alpha[4], const uint64_t beta[4],
+                          const uint64_t gamma[4], size_t n, void *stream) {
+    return guarded([&] {
+        if (!d_in || !zh_inv || !alpha || !beta || !gamma || (n && !d_out)) return invalid("zk_plonk_quotient_dev: null pointer");
+        if (period == 0 || period > 8 || (period & (period - 1))) return invalid("zk_plonk_quotient_dev: period must be 1, 2, 4 or 8");
+        if (!scalars_canonical(zh_inv, period) || !scalars_canonical(alpha, 1) || !scalars_canonical(beta, 1) || !scalars_canonical(gamma, 1))
+            return invalid("zk_plonk_quotient_dev: scalar not canonical (>= r)");
+        for (int k = 0; k < 15; k++)
+            if (n && !d_in[k]) return invalid("zk_plonk_quotient_dev: null input vector");
+        plonk_quotient(d_out, d_in, zh_inv, period, alpha, beta, gamma, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_frvec_create(zk_frvec **ws) {
     return guarded([&] {
         if (!ws) return invalid("zk_frvec_create: null pointer");

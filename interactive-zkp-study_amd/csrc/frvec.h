@@ -13,6 +13,11 @@ void fr_lincomb(void *d_out, const void *const *d_in, const uint64_t *coeffs, un
 // out[i] = a[i] * b[i]
 void fr_mul(void *d_out, const void *d_a, const void *d_b, size_t n, hipStream_t st);
 
+// Fused PLONK quotient on the evaluation coset; d_in: 15 device vectors a b c z zw | ql qr qo qm qc | s1 s2 s3 | x l1;
+// zh_inv: `period` HOST elements (1 / Z_H on the coset repeats with that period).
+void plonk_quotient(void *d_out, const void *const *d_in, const uint64_t *zh_inv, unsigned period, const uint64_t alpha[4], const uint64_t beta[4],
+                    const uint64_t gamma[4], size_t n, hipStream_t st);
+
 // Scratch owned by whoever issues the calls (one per thread of use): power tables and the scan's per-level chunk totals.
 struct FrVecScratch {
     DevBuf tables;

@@ -61,6 +61,48 @@ __global__ __launch_bounds__(256) void fr_powers_kernel(uint32_t *__restrict__ x
     stc(x + i * 8, fe_mul(ldc(x + i * 8), w));
 }
 
+// ------------------------------------------------------------------------------ PLONK quotient, fused
+// t[i] = (gate + alpha * (num - den) + alpha^2 * (z - 1) * L1) / Z_H on the evaluation coset (zkp/plonk/prover/round3.py:114-147
+// builds the same numerator by polynomial products and divides by Z_H with poly_div):
+//   gate = q_L a + q_R b + q_O c + q_M a b + q_C
+//   num  = (a + beta x + gamma)(b + beta K1 x + gamma)(c + beta K2 x + gamma) z(x)          K1 = 2, K2 = 3
+//   den  = (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma) z(omega x)
+// Inputs are plain (canonical) values; a Montgomery product of two plain values carries 1/R, so the terms are brought to the
+// common scale 1/R by constants prepared on the host (alpha R^3, alpha^2 R, R^2) and the last product by zh_inv R^2 lands on
+// the plain result: 21 multiplications per element, one pass over the 15 input vectors.
+struct QuotientArgs {
+    const uint32_t *in[15];  // a b c z zw | ql qr qo qm qc | s1 s2 s3 | x l1
+    Fr beta_m, gamma, alpha_r3, alpha2_r, zh_inv_r2[8];
+    uint32_t period;
+};
+__global__ __launch_bounds__(256) void plonk_quotient_kernel(uint32_t *__restrict__ out, QuotientArgs A, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    auto ld = [&](int k) { return ldc(A.in[k] + i * 8); };
+    auto add2 = [](const Fr &p, const Fr &q) { Fr r = fe_add(p, q); fe_wreduce<4>(r); return r; };   // < 2r
+    const Fr a = ld(0), b = ld(1), c = ld(2), z = ld(3), zw = ld(4);
+    // gate / R
+    Fr gate = add2(fe_mul(ld(5), a), fe_mul(ld(6), b));
+    gate = add2(gate, fe_mul(ld(7), c));
+    gate = add2(gate, fe_to_mont(fe_mul(fe_mul(a, b), ld(8))));     // (ab qm / R^2) * R^2 / R
+    gate = add2(gate, fe_from_mont(ld(9)));                          // q_C / R
+    // num / R^3 and den / R^3
+    const Fr bx = fe_mul(ld(13), A.beta_m);                          // beta x, plain, < 2r
+    const Fr bx2 = add2(bx, bx), bx3 = add2(bx2, bx);
+    auto term = [&](const Fr &w, const Fr &bs) { return add2(add2(w, bs), A.gamma); };
+    Fr num = fe_mul(fe_mul(fe_mul(term(a, bx), term(b, bx2)), term(c, bx3)), z);
+    Fr den = fe_mul(fe_mul(fe_mul(term(a, fe_mul(ld(10), A.beta_m)), term(b, fe_mul(ld(11), A.beta_m))), term(c, fe_mul(ld(12), A.beta_m))), zw);
+    Fr diff = fe_sub_k<2>(num, den);                                 // num - den + 2r < 4r
+    fe_wreduce<4>(diff);
+    Fr tot = add2(gate, fe_mul(diff, A.alpha_r3));                   // alpha (num - den) / R
+    Fr one_plain = Fr::zero();
+    one_plain.l[0] = 1u;
+    Fr zm1 = fe_sub_k<2>(z, one_plain);                              // z - 1 + 2r
+    fe_wreduce<4>(zm1);
+    tot = add2(tot, fe_mul(fe_mul(zm1, ld(14)), A.alpha2_r));        // alpha^2 (z - 1) L1 / R
+    stc(out + i * 8, fe_mul(tot, A.zh_inv_r2[i % A.period]));        // (S / R) * zh_inv R^2 / R
+}
+
 // ------------------------------------------------------------------------------ scans
 // Values are kept in the form in which `op` is one field operation: plain for +, Montgomery for * (mont_mul of two
 // Montgomery values is the Montgomery product).  Bounds: op results < 2r for both.
@@ -199,6 +241,28 @@ void fr_mul(void *d_out, const void *d_a, const void *d_b, size_t n, hipStream_t
     if (n == 0) return;
     hipLaunchKernelGGL(fr_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out), static_cast<const uint32_t *>(d_a),
                        static_cast<const uint32_t *>(d_b), n);
+    ZK_HIP(hipGetLastError());
+}
+
+void plonk_quotient(void *d_out, const void *const *d_in, const uint64_t *zh_inv, unsigned period, const uint64_t alpha[4], const uint64_t beta[4],
+                    const uint64_t gamma[4], size_t n, hipStream_t st) {
+    if (period == 0 || period > 8 || (period & (period - 1))) throw std::runtime_error("zk_plonk_quotient_dev: period must be 1, 2, 4 or 8");
+    if (n == 0) return;
+    QuotientArgs A;
+    memset(&A, 0, sizeof(A));
+    for (int k = 0; k < 15; k++) A.in[k] = static_cast<const uint32_t *>(d_in[k]);
+    auto dev_mont = [](const HFr &plain) { return fe_to_mont(plain).to_dev(); };   // x -> x R (device radix)
+    const HFr al = host_fr(alpha);
+    A.beta_m = dev_mont(host_fr(beta));
+    uint32_t w[8];
+    memcpy(w, gamma, 32);
+    A.gamma = fe_from_words<FrTag>(w);
+    A.alpha_r3 = fe_to_mont(fe_to_mont(dev_mont(al)));              // device arithmetic compiled for the host: x R -> x R^2 -> x R^3
+    const HFr am = fe_to_mont(al);
+    A.alpha2_r = fe_mul(am, am).to_dev();                            // host Montgomery square (alpha R)(alpha R) / R = alpha^2 R, then device radix
+    for (unsigned k = 0; k < period; k++) A.zh_inv_r2[k] = fe_to_mont(dev_mont(host_fr(zh_inv + 4 * k)));
+    A.period = period;
+    hipLaunchKernelGGL(plonk_quotient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out), A, n);
     ZK_HIP(hipGetLastError());
 }
 

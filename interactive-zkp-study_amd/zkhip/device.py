@@ -172,3 +172,12 @@ class FrVec:
     def scan(self, d_data, n, product=False, reverse=False, stream=0):
         """In-place inclusive scan: running sums (product=False) or products; reverse: from the last element down."""
         _lib.check(_lib.load().zk_fr_scan_dev(self._h, d_data, n, 1 if product else 0, 1 if reverse else 0, stream))
+
+
+def plonk_quotient(d_out, d_ins, zh_inv, alpha, beta, gamma, n, stream=0):
+    """Fused PLONK round-3 quotient on the evaluation coset (zk_plonk_quotient_dev); d_ins: the 15 device vectors
+    a b c z zw | q_L q_R q_O q_M q_C | s1 s2 s3 | x L1, zh_inv: the `period` values of 1 / Z_H."""
+    ptrs = (ctypes.c_void_p * 15)(*[ctypes.c_void_p(int(p)) for p in d_ins])
+    zi = _lib.ints_to_limbs([int(v) for v in zh_inv])
+    sc = _lib.ints_to_limbs([int(alpha), int(beta), int(gamma)])
+    _lib.check(_lib.load().zk_plonk_quotient_dev(d_out, ptrs, _lib.ptr(zi), len(zh_inv), _lib.ptr(sc[0:1]), _lib.ptr(sc[1:2]), _lib.ptr(sc[2:3]), n, stream))

@@ -6,7 +6,8 @@ selector / permutation polynomials and the SRS are device buffers and the rounds
 
   interpolation, coset evaluation      zk_ntt_dev (NttPlan)
   commitments                          zk_msm_submit / collect (MsmPlan, up to three in flight)
-  a + beta*id + gamma, gate terms ...  zk_fr_lincomb_dev, zk_fr_mul_dev
+  a + beta*id + gamma, r(x), ...       zk_fr_lincomb_dev, zk_fr_mul_dev
+  round-3 quotient on the coset        zk_plonk_quotient_dev (one fused pass over 15 vectors)
   grand product z                      prefix products of the numerators, suffix products of the denominators (zk_fr_scan_dev)
   p(zeta)                              zk_fr_scale_powers_dev + running sum
   (p(x) - p(z)) / (x - z)              q[i] = z^-(i+1) * sum_{j>i} c[j] z^j: scale, suffix sums, scale
@@ -19,7 +20,7 @@ import secrets
 import numpy as np
 
 from .. import _lib
-from ..device import FrVec, MsmPlan, NttPlan
+from ..device import FrVec, MsmPlan, NttPlan, plonk_quotient
 from ..field import FR, CURVE_ORDER as R, get_root_of_unity, limbs_to_g1
 from .permutation import K1, K2
 from .prover import COSET_K, Proof, linearisation_scalars
@@ -86,7 +87,7 @@ class DevicePlonk:
         self.coset["l1"] = self._coset(l1_coef)
         w_big = int(get_root_of_unity(self.size))
         zh_inv = [pow((pow(COSET_K * pow(w_big, i, R) % R, n, R) - 1) % R, -1, R) for i in range(self.step)]
-        self.coset["zh_inv"] = _dev(_limbs(zh_inv)).repeat(self.size // self.step, 1).contiguous()  # x^n has period `step` on the coset
+        self.zh_inv = zh_inv                                     # 1 / Z_H: x^n has period `step` on the coset
 
     # ---- helpers -------------------------------------------------------------------------------------------
     def _zeros(self, rows):
@@ -217,27 +218,10 @@ class DevicePlonk:
         cs = self.coset
         ea, eb, ec, ez = (self._coset(p) for p in (wires[0], wires[1], wires[2], z))
         ezw = torch.roll(ez, -step, 0)                                           # z(omega x): omega = w_big^step
-        tot, t1, t2 = self._zeros(size), self._zeros(size), self._zeros(size)
-        self._mul(t1, ea, eb, size)
-        self._mul(tot, t1, cs["q_m"], size)
-        for sel, ev in (("q_l", ea), ("q_r", eb), ("q_o", ec)):
-            self._mul(t1, cs[sel], ev, size)
-            self._lin(tot, [tot, t1], [1, 1], size)
-        self._lin(tot, [tot, cs["q_c"]], [1, 1], size)                           # + PI(x) = 0
-        for sign, other, z_side in ((1, [cs["x"], cs["x"], cs["x"]], ez), (R - 1, [cs["s_sigma1"], cs["s_sigma2"], cs["s_sigma3"]], ezw)):
-            for j, (ev, idc) in enumerate(zip((ea, eb, ec), (1, k1, k2))):
-                coef = be * (idc if sign == 1 else 1) % R
-                self._lin(t2, [ev, other[j]], [1, coef], size, ga)
-                if j == 0:
-                    t1.copy_(t2)
-                else:
-                    self._mul(t1, t1, t2, size)
-            self._mul(t1, t1, z_side, size)
-            self._lin(tot, [tot, t1], [1, al * sign % R], size)
-        self._lin(t1, [ez], [1], size, R - 1)                                    # z - 1
-        self._mul(t1, t1, cs["l1"], size)
-        self._lin(tot, [tot, t1], [1, al * al % R], size)
-        self._mul(tot, tot, cs["zh_inv"], size)
+        tot = torch.empty_like(ez)
+        plonk_quotient(tot.data_ptr(), [t.data_ptr() for t in (ea, eb, ec, ez, ezw, cs["q_l"], cs["q_r"], cs["q_o"], cs["q_m"], cs["q_c"],
+                                                                 cs["s_sigma1"], cs["s_sigma2"], cs["s_sigma3"], cs["x"], cs["l1"])],
+                       self.zh_inv, al, be, ga, size, st)                         # one pass over the 15 vectors (zk_plonk_quotient_dev)
         self.ntt_big.run(tot.data_ptr(), True, COSET_K, st)
         if bool(tot[3 * n + 6:].any()):
             raise ValueError("constraint polynomial is not divisible by Z_H: circuit or witness is inconsistent")
