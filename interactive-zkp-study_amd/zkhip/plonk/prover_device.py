@@ -88,6 +88,7 @@ class DevicePlonk:
         w_big = int(get_root_of_unity(self.size))
         zh_inv = [pow((pow(COSET_K * pow(w_big, i, R) % R, n, R) - 1) % R, -1, R) for i in range(self.step)]
         self.zh_inv = zh_inv                                     # 1 / Z_H: x^n has period `step` on the coset
+        self.work = [self._zeros(self.size) for _ in range(6)]   # per-proof coset buffers: a, b, c, z, z(omega x), t
 
     # ---- helpers -------------------------------------------------------------------------------------------
     def _zeros(self, rows):
@@ -100,9 +101,12 @@ class DevicePlonk:
         self.ntt_n.run(out.data_ptr(), True, None, self.st)
         return out
 
-    def _coset(self, coef):
-        """Coefficient buffer -> evaluations on the coset k*H' (size, 4)."""
-        out = self._zeros(self.size)
+    def _coset(self, coef, out=None):
+        """Coefficient buffer -> evaluations on the coset k*H' (size, 4), into `out` when given."""
+        if out is None:
+            out = self._zeros(self.size)
+        else:
+            out.zero_()
         m = min(coef.shape[0], self.size)
         out[:m] = coef[:m]
         self.ntt_big.run(out.data_ptr(), False, COSET_K, self.st)
@@ -181,7 +185,11 @@ class DevicePlonk:
 
         # round 1 (round1.py:55-108)
         wires = [self._blinded(self._interpolate(col), blind[2 * i:2 * i + 2]) for i, col in enumerate(cols)]
-        for name, comm in zip(("a_comm", "b_comm", "c_comm"), self._commit_many([(w, n + 2) for w in wires])):
+        tickets = [self.msm.submit(w.data_ptr(), self.srs.data_ptr(), n + 2, st) for w in wires]
+        ea, eb, ec = (self._coset(w, buf) for w, buf in zip(wires, self.work[:3]))   # round 3's coset evaluations of the wires need no challenge: under the MSMs
+        for name, t in zip(("a_comm", "b_comm", "c_comm"), tickets):
+            limbs, inf = self.msm.collect_limbs(t)
+            comm = None if inf else limbs_to_g1(limbs)[0]
             setattr(pr, name, comm)
             tr.append_point(name.encode(), comm)
 
@@ -209,16 +217,20 @@ class DevicePlonk:
         self._mul(z_ev[1:], num[:n - 1], den[1:], n - 1)                         # z_i = prod_{j<i} num_j / den_j
         self._lin(z_ev[1:], [z_ev[1:]], [pow(den_total, -1, R)], n - 1)
         z = self._blinded(self._interpolate(z_ev), blind[6:9])
-        pr.z_comm = self._commit(z, n + 3)
+        t_z = self.msm.submit(z.data_ptr(), self.srs.data_ptr(), n + 3, st)
+        ez = self._coset(z, self.work[3])                    # likewise under the commitment of z
+        ezw = self.work[4]
+        ezw[:size - step] = ez[step:]                        # z(omega x): omega = w_big^step
+        ezw[size - step:] = ez[:step]
+        limbs, inf = self.msm.collect_limbs(t_z)
+        pr.z_comm = None if inf else limbs_to_g1(limbs)[0]
         tr.append_point(b"z_comm", pr.z_comm)
 
         # round 3 (round3.py:80-187): t = (gate + alpha perm + alpha^2 (z - 1) L1) / Z_H on the coset
         alpha = tr.challenge_scalar(b"alpha")
         al = int(alpha)
         cs = self.coset
-        ea, eb, ec, ez = (self._coset(p) for p in (wires[0], wires[1], wires[2], z))
-        ezw = torch.roll(ez, -step, 0)                                           # z(omega x): omega = w_big^step
-        tot = torch.empty_like(ez)
+        tot = self.work[5]
         plonk_quotient(tot.data_ptr(), [t.data_ptr() for t in (ea, eb, ec, ez, ezw, cs["q_l"], cs["q_r"], cs["q_o"], cs["q_m"], cs["q_c"],
                                                                  cs["s_sigma1"], cs["s_sigma2"], cs["s_sigma3"], cs["x"], cs["l1"])],
                        self.zh_inv, al, be, ga, size, st)                         # one pass over the 15 vectors (zk_plonk_quotient_dev)
