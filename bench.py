@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
     ap.add_argument("--plonk-log-n", type=int, default=20, help="log2 gates of the secondary device-resident PLONK prove() timing (0 = skip)")
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
+    ap.add_argument("--shard-total-log", type=int, default=26, help="N > 1 only: log2 points of the secondary ONE-MSM-sharded-over-all-GPUs "
+                    "measurement (BASELINE.json configs[4]; 0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
     args = ap.parse_args()
 
@@ -176,6 +178,46 @@ def main():
     extra = {"verified_closed_form": bool(verified), "window_bits": plan.window_bits(n),
              "stage_ms": {"prepare": round(float(stage[0]), 4), "sort": round(float(stage[1]), 4), "accumulate": round(float(stage[2]), 4),
                           "reduce": round(float(stage[3]), 4)}}
+
+    # ---- secondary, N > 1: ONE MSM of 2^26 points sharded over the ranks by contiguous chunks (BASELINE.json configs[4]).
+    # Every rank joins in (collectives inside); any failure is reported on every rank alike before the collectives start.
+    if dist_on and args.shard_total_log:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from bench_sizes import arithmetic_dot, arithmetic_points
+            from zkhip.distributed import shard_range
+            n_tot = 1 << args.shard_total_log
+            lo, hi = shard_range(n_tot, rank, world)
+            m_loc = hi - lo
+            k0, dd = 0x1234567890ABCDEF >> 1, 0x9E3779B1
+            s_loc = random_scalars(np.random.default_rng(0x5EEDB260 + rank), m_loc)
+            p_loc = arithmetic_points(lib, m_loc, k0 + lo * dd, dd)          # P_i = (k0 + i d) G for the global index i
+            d_s2 = torch.from_numpy(s_loc.view(np.int64)).to(dev)
+            d_p2 = torch.from_numpy(p_loc.view(np.int64)).to(dev)
+            plan2 = MsmPlan(_lib.GROUP_G1, m_loc)
+            ok_all = torch.ones(1, device=dev)
+        except Exception as exc:                                              # noqa: BLE001 -- keep the ranks in step
+            ok_all = torch.zeros(1, device=dev)
+            shard_err = repr(exc)
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+        if float(ok_all.item()) == 1.0:
+            one = lambda: sharded_msm(_lib.GROUP_G1, plan2.run_partial(d_s2.data_ptr(), d_p2.data_ptr(), m_loc, stream), device=dev)
+            one()
+            fence()
+            t_s = time.perf_counter()
+            sreps = 3
+            for _ in range(sreps):
+                got_tot = one()
+            fence()
+            sms = (time.perf_counter() - t_s) / sreps * 1e3
+            dots = [None] * world
+            dist.all_gather_object(dots, arithmetic_dot(s_loc, k0 + lo * dd, dd))
+            extra["sharded_one_msm"] = {"log_n_total": args.shard_total_log, "points_per_gpu": m_loc, "ms_per_msm": round(sms, 3),
+                                        "points_per_s": n_tot / (sms * 1e-3), "verified_closed_form": bool(got_tot == ec_mul(G1, sum(dots) % R_MOD))}
+            plan2.close()
+            del d_s2, d_p2
+        else:
+            extra["sharded_one_msm"] = {"error": "setup failed on some rank"}
 
     # ---- secondary: NTT forward + inverse round trip (BASELINE.json configs[2])
     if args.ntt_log_n and rank == 0:
