@@ -1,21 +1,23 @@
 // msm_impl.h -- Pippenger multi-scalar multiplication on BN254 G1 / G2 for gfx950.
 //
 // Replaces the reference's scalar-mul-and-add loops (zkp/plonk/kzg.py:59-65,
-// zkp/groth16/proving.py:23-75).  Pipeline (all kernels on one stream, no host sync until the
-// final 32 KiB read-back):
+// zkp/groth16/proving.py:23-75).  One MSM = one pass through these kernels on the stream of the plan
+// lane it was submitted to, with no host synchronisation until the 36 KiB read-back:
 //
-//   prepare      one thread per point: canonical affine -> Montgomery affine (workspace, resident
-//                for all windows), scalar -> W signed c-bit digits (int16, window-major).
-//   accumulate   one workgroup owns NT consecutive buckets of one window.  It streams that
-//                window's digit row (L2-resident), stages the matching (point index, sign)
-//                entries in LDS bucket lists (LDS-atomic counting sort), then each thread adds
-//                its bucket's points in XYZZ mixed coordinates (8M+2S per point).
-//   reduce       sum_j (j+1)*B_j per window without any serial running sum: log2(nb) "pair"
-//                levels (L[l+1][j] = L[l][2j] + L[l][2j+1]) plus plain sums O_l of the odd
-//                entries of every level (serial-4 per lane + wavefront __shfl tree), since
-//                sum_j j*B_j = sum_l 2^l * O_l.
-//   fold (host)  the W*(c) window/level sums (32 KiB) are read back and combined by one
-//                254-doubling Horner pass on the host (a single GPU thread would be latency-bound).
+//   prepare      one thread per point: canonical affine -> Montgomery affine packed to one 64-byte line (resident
+//                for all windows), scalar -> W signed c-bit digits (int16, window-major), per-cell histogram.
+//   bucket sort  scan -> partition (by cell = 256 buckets of one window, LDS-staged) -> segcount / segscatter
+//                (per-cell LDS counting sort, up to 8 workgroups per cell) -> rank (buckets by list length).
+//   accumulate   one thread per bucket, one wavefront per workgroup, lists of equal length side by side; XYZZ mixed
+//                additions (8M+2S) with a two-deep load pipeline.  Lists longer than heavy_th go to the heavy-bucket
+//                kernels (wavefront tasks of 64 segments, __shfl trees).
+//   reduce       sum_j (j+1)*B_j per window without any serial running sum, in place: pair levels plus plain-sum trees
+//                over the odd entries of every level (sum_j j*B_j = sum_l 2^l * O_l).
+//   fold (host)  the W*c window/level sums are read back and combined by one 254-doubling Horner pass on the host
+//                (a single GPU thread would be latency-bound); it hides behind the next MSM's kernels.
+//
+// A plan holds three lanes (workspace + stream each): consecutive submissions overlap on the GPU, and MSMs of more
+// than 2^22 points run as 2^22-point chunks through the same lanes.
 #pragma once
 #include "common.h"
 #include "curve.h"
@@ -95,10 +97,11 @@ template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint3
 //   partition  coarse radix pass: every (window, point) entry is written to its cell's segment
 //              (index | sign << 31 in e_idx, bucket-in-cell byte in e_loc); a workgroup reserves one
 //              contiguous span per cell, so writes are short runs, never single scattered words.
-//   segsort    one workgroup per cell: counts its 256 buckets (-> counts[], bucket_off[]), then sorts
-//              the segment chunk by chunk entirely in LDS (LDS-atomic ranks, block scan, staging
-//              buffer) and writes each chunk out as per-bucket runs -- coalesced reads, run-coalesced
-//              writes, no global atomics.
+//   segcount / segscatter
+//              up to SEG_Z workgroups per cell take its 4096-entry chunks round-robin: count the 256 buckets
+//              (-> counts[], bucket_off[]), then sort every chunk entirely in LDS (LDS-atomic ranks, block
+//              scan, staging buffer) and write it out as per-bucket runs -- coalesced 16-byte reads,
+//              run-coalesced writes, no global atomics.
 //   rank       counting sort of the bucket ids by list length, longest first (perm[]), so that the
 //              accumulate kernel's wavefronts own equal-length lists; also registers heavy buckets.
 constexpr int SEG_BUCKETS = 256;
