@@ -476,6 +476,18 @@ template <class F>
 __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ lst, uint32_t len) {
     Xyzz<F> acc = Xyzz<F>::inf();
     if (len == 0) return acc;
+    if (F::CANON_WORDS == 16) {
+        // G2: the working set of the F_p^2 addition leaves no registers for a prefetched point; two wavefronts per SIMD
+        // cover the load latency instead
+#pragma unroll 1
+        for (uint32_t k = 0; k < len; k++) {
+            const uint32_t e = lst[k];
+            Affine<F> p = unpack_affine(pts[e & 0x7fffffffu]);
+            if (e >> 31) p.y = fe_neg<2>(p.y);
+            xyzz_add_affine(acc, p);
+        }
+        return acc;
+    }
     // Two-deep software pipeline, branch-free loads (indices clamp to the last entry): at the top of every
     // iteration the loads of the NEXT point (its index arrived an iteration ago) and of the index after it are
     // issued, then the current point is added -- no load is ever waited for in the iteration that issued it.
@@ -498,7 +510,7 @@ __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ 
 }
 
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts,
                                                              const uint32_t *__restrict__ bucket_off,
                                                              const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
@@ -533,7 +545,7 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<
 // Heavy buckets, stage 1: one wavefront per task = 64 consecutive HEAVY_SEG-entry segments of one bucket's
 // list; every lane sums its segment, a __shfl tree leaves the task's partial sum in lane 0.
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 1)) void msm_heavy_segments_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B,
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_heavy_segments_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B,
                                                                                             Xyzz<F> *__restrict__ partial) {
     const uint32_t ntasks = min(B.heavy_ctr[0], B.heavy_cap), lane = threadIdx.x;
     for (uint32_t wt = blockIdx.x; wt < ntasks; wt += gridDim.x) {
