@@ -471,46 +471,25 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbu
 // One thread per bucket, one wavefront per workgroup, buckets taken in order of decreasing list
 // length (perm[]): the 64 lanes of a wavefront own lists of (nearly) equal length, wavefronts retire
 // independently and the longest lists start first.  Each thread adds its points in XYZZ mixed
-// coordinates (8M+2S per point), the next point and the index after it being fetched under the current add.
+// coordinates (8M+2S per point).
 template <class F>
 __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ lst, uint32_t len) {
+    // No software prefetch: holding the next point would cost the registers that let four (G1) / two (G2) wavefronts
+    // share a SIMD, and those wavefronts hide the gather latency better than a prefetch under three / one did
+    // (G1 accumulate 1.30 -> 1.27 ms, G2 4.40 -> 3.63 ms).
     Xyzz<F> acc = Xyzz<F>::inf();
-    if (len == 0) return acc;
-    if (F::CANON_WORDS == 16) {
-        // G2: the working set of the F_p^2 addition leaves no registers for a prefetched point; two wavefronts per SIMD
-        // cover the load latency instead
-#pragma unroll 1
-        for (uint32_t k = 0; k < len; k++) {
-            const uint32_t e = lst[k];
-            Affine<F> p = unpack_affine(pts[e & 0x7fffffffu]);
-            if (e >> 31) p.y = fe_neg<2>(p.y);
-            xyzz_add_affine(acc, p);
-        }
-        return acc;
-    }
-    // Two-deep software pipeline, branch-free loads (indices clamp to the last entry): at the top of every
-    // iteration the loads of the NEXT point (its index arrived an iteration ago) and of the index after it are
-    // issued, then the current point is added -- no load is ever waited for in the iteration that issued it.
-    const uint32_t last = len - 1;
-    uint32_t e = lst[0];
-    uint32_t e_n = lst[min(1u, last)];
-    PackedAffine<F> pk = pts[e & 0x7fffffffu];
 #pragma unroll 1
     for (uint32_t k = 0; k < len; k++) {
-        const PackedAffine<F> pk_n = pts[e_n & 0x7fffffffu];
-        const uint32_t e_nn = lst[min(k + 2, last)];
-        Affine<F> p = unpack_affine(pk);
+        const uint32_t e = lst[k];
+        Affine<F> p = unpack_affine(pts[e & 0x7fffffffu]);
         if (e >> 31) p.y = fe_neg<2>(p.y);
         xyzz_add_affine(acc, p);
-        e = e_n;
-        e_n = e_nn;
-        pk = pk_n;
     }
     return acc;
 }
 
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ counts,
                                                              const uint32_t *__restrict__ bucket_off,
                                                              const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
