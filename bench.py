@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--shard-total-log", type=int, default=26, help="N > 1 only: log2 points of the secondary ONE-MSM-sharded-over-all-GPUs "
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
+    ap.add_argument("--dist-ntt-log-n", type=int, default=24, help="N > 1 only: log2 size of the single NTT spread over all GPUs (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
     args = ap.parse_args()
 
@@ -219,29 +220,66 @@ def main():
         else:
             extra["sharded_one_msm"] = {"error": "setup failed on some rank"}
 
-    # ---- secondary: NTT forward + inverse round trip (BASELINE.json configs[2])
-    if args.ntt_log_n and rank == 0:
+    # ---- secondary: NTT forward + inverse round trip (BASELINE.json configs[2]).  With N > 1 every rank transforms a
+    # polynomial of its own (batch-parallel mode: no exchange) between barriers; the aggregate is N transforms per span.
+    if args.ntt_log_n:
         L = args.ntt_log_n
         m = 1 << L
-        coeffs = random_scalars(np.random.default_rng(0x5EEDB255), m)
+        coeffs = random_scalars(np.random.default_rng(0x5EEDB255 + rank), m)
         d = torch.from_numpy(coeffs.view(np.int64)).to(dev)
         ref = d.clone()
         nplan = NttPlan(L)
         for _ in range(2):
             nplan.run(d.data_ptr(), False, None, stream)
             nplan.run(d.data_ptr(), True, None, stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
+        fence()
+        tn0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             nplan.run(d.data_ptr(), False, None, stream)
             nplan.run(d.data_ptr(), True, None, stream)
         e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / (2 * reps)  # per transform
+        fence()
+        span = time.perf_counter() - tn0
+        ms = e0.elapsed_time(e1) / (2 * reps)  # per transform, this rank's device time
+        exact = bool(torch.equal(d, ref))
+        if dist_on:
+            tt = torch.tensor([span, 0.0 if exact else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            span, exact = float(tt[0].item()), float(tt[1].item()) == 0.0
         extra["ntt"] = {"log_n": L, "ms_per_transform": round(ms, 4), "elements_per_s": m / (ms * 1e-3),
                         "algorithmic_GBps": 64.0 * m / (ms * 1e-3) / 1e9, "hbm_frac": 64.0 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "roundtrip_exact": bool(torch.equal(d, ref))}
+                        "roundtrip_exact": exact}
+        if dist_on:
+            agg = world * 2 * reps * m / span   # wall clock between barriers (includes launch latency), all ranks
+            extra["ntt"]["all_gpus"] = {"mode": "one polynomial per GPU, no exchange", "elements_per_s": agg,
+                                        "hbm_frac_per_gpu": 64.0 * agg / world / 1e9 / HBM_PEAK_GBS}
+        del d, ref
+        # ONE transform of 2^24 points spread over the ranks (four-step, one all-to-all; zkhip.distributed.DistNtt)
+        if dist_on and args.dist_ntt_log_n:
+            from zkhip.distributed import DistNtt
+            dn = DistNtt(args.dist_ntt_log_n)
+            rows, cols = dn.local_shape_in()
+            x0 = torch.from_numpy(random_scalars(np.random.default_rng(0x5EEDB270 + rank), rows * cols).view(np.int64).reshape(rows, cols, 4)).to(dev)
+            x = x0.clone()
+            back = dn.inverse(dn.forward(x))
+            ok_rt = bool(torch.equal(back, x0))
+            x = x0.clone()
+            fence()
+            td0 = time.perf_counter()
+            dreps = 3
+            for _ in range(dreps):
+                y = dn.forward(x)
+                x = y if dn.l1 == dn.l2 else x0.clone()     # even log n: the output layout is the input layout again
+            fence()
+            dms = (time.perf_counter() - td0) / dreps * 1e3
+            tt = torch.tensor([dms, 0.0 if ok_rt else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            extra["dist_ntt"] = {"log_n": args.dist_ntt_log_n, "ms_per_forward": round(float(tt[0].item()), 4),
+                                 "elements_per_s": (1 << args.dist_ntt_log_n) / (float(tt[0].item()) * 1e-3), "roundtrip_exact": float(tt[1].item()) == 0.0}
+            del x, x0, back, y
 
     # ---- secondary: "witness-like" scalars: half the scalars are 0 or 1, the rest uniform
     if rank == 0 and world == 1 and not args.no_witness_like:
