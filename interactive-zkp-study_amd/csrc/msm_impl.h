@@ -652,11 +652,12 @@ __global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz
 
 // ------------------------------------------------------------------------------ host side
 static int pick_window_bits(size_t n) {
-    // widths whose top window is not degenerate (255 = W*c - slack: the top window of c = 13 / 15 / 16
-    // still holds 7 / 14 / 14 scalar bits; c = 9, 11, 12, 14 would leave it 1-2 bits = 1-3 giant buckets)
-    if (n <= (1u << 8)) return 8;
-    if (n <= (1u << 11)) return 10;
-    if (n <= (1u << 14)) return 13;
+    // Measured on MI355X (blocking and pipelined, n = 2^2 .. 2^19): below ~2^9 points everything is launch latency and the
+    // 8-bit windows' short reduction tree wins; from there to 2^17 c = 15 beats every narrower width -- most of its 17 x 2^14
+    // buckets stay empty and cost the reduction next to nothing, while the accumulate kernel runs three windows fewer
+    // than with c = 13 (2^12 points: 0.97 -> 0.63 ms); 16 from 2^18.  All three keep a non-degenerate top window
+    // (255 = W*c - slack leaves it 7 / 15 / 15 scalar bits; c = 9, 11, 12, 14 would leave 1-3 giant buckets).
+    if (n <= (1u << 9)) return 8;
     if (n <= (1u << 17)) return 15;
     return 16;
 }
@@ -708,7 +709,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         cap_n = std::min(max_n, chunk_points());
         const size_t n_pad = pad_n(cap_n);
         // worst case over the window choices available to n <= max_n
-        const int cs[5] = {8, 10, 13, 15, 16};
+        const int cs[3] = {8, 15, 16};
         for (int c : cs) {
             if (c > pick_window_bits(cap_n)) continue;
             size_t W = (255 + c - 1) / c, nb = (size_t)1 << (c - 1);
@@ -871,8 +872,6 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(L, 0);
         switch (c) {
             case 8: launch_prepare<8>(L, sc, pt, (uint32_t)n, n_pad); break;
-            case 10: launch_prepare<10>(L, sc, pt, (uint32_t)n, n_pad); break;
-            case 13: launch_prepare<13>(L, sc, pt, (uint32_t)n, n_pad); break;
             case 15: launch_prepare<15>(L, sc, pt, (uint32_t)n, n_pad); break;
             default: launch_prepare<16>(L, sc, pt, (uint32_t)n, n_pad); break;
         }

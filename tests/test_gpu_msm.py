@@ -39,7 +39,7 @@ def msm_g2(S, Pts):
     return out
 
 
-# sizes straddle the window-width switches (c = 8 | 10 | 13 | 15 | 16 at n = 2^8 / 2^11 / 2^14 / 2^17) and block edges
+# sizes straddle the window-width switches (c = 8 | 15 | 16 at n = 2^9 / 2^17) and block edges
 @pytest.mark.parametrize("n", [1, 2, 3, 17, 255, 256, 257, 512, 513, 1000, 2048, 2049, 4095, 4096, 4097, 16384, 16385, 40000])
 def test_g1_msm_bit_exact_vs_oracle(n):
     rng = np.random.default_rng(1000 + n)
