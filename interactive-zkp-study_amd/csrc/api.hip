@@ -303,7 +303,7 @@ int zk_msm_plan_create(int group, size_t max_n, zk_msm_plan **plan) {
         int rc = require_device();
         if (rc) return rc;
         zk_msm_plan *p = new zk_msm_plan;
-        p->impl.reset(msm_plan_new(group, max_n));
+        p->impl.reset(msm_plan_new(group, max_n, true));
         *plan = p;
         return ZK_OK;
     });

@@ -21,10 +21,11 @@ struct MsmPlanBase {
     virtual int collect_affine(int ticket, uint64_t *out_xy, int *out_is_inf) = 0;
     virtual int collect_partial(int ticket, uint64_t *out_xyzz) = 0;
 };
-MsmPlanBase *msm_plan_new_g1(size_t max_n);
-MsmPlanBase *msm_plan_new_g2(size_t max_n);
-inline MsmPlanBase *msm_plan_new(int group, size_t max_n) {
-    return group == ZK_GROUP_G1 ? msm_plan_new_g1(max_n) : group == ZK_GROUP_G2 ? msm_plan_new_g2(max_n) : nullptr;
+// all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use
+MsmPlanBase *msm_plan_new_g1(size_t max_n, bool all_lanes);
+MsmPlanBase *msm_plan_new_g2(size_t max_n, bool all_lanes);
+inline MsmPlanBase *msm_plan_new(int group, size_t max_n, bool all_lanes = false) {
+    return group == ZK_GROUP_G1 ? msm_plan_new_g1(max_n, all_lanes) : group == ZK_GROUP_G2 ? msm_plan_new_g2(max_n, all_lanes) : nullptr;
 }
 
 // Host XYZZ (Montgomery) -> canonical affine limbs; infinity -> zeros + flag.

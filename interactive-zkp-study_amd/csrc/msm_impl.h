@@ -704,7 +704,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         int npend = 0;
     } big;
 
-    explicit MsmPlanImpl(size_t max_n_) : max_n(max_n_) {
+    explicit MsmPlanImpl(size_t max_n_, bool all_lanes = false) : max_n(max_n_) {
         group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
         cap_n = std::min(max_n, chunk_points());
         const size_t n_pad = pad_n(cap_n);
@@ -721,7 +721,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         // them and sum ceil(len / HEAVY_WAVE) <= entries / HEAVY_WAVE + (heavy buckets) wavefront tasks; entries <= W * n_pad
         heavy_cap = (uint32_t)(dig_bytes / sizeof(int16_t) / HEAVY_SEG + dig_bytes / sizeof(int16_t) / HEAVY_WAVE + 64);
         nlanes = 3;
-        prepare_lane(lanes[0]);
+        for (int i = 0; i < (all_lanes ? nlanes : 1); i++) prepare_lane(lanes[i]);
     }
     void prepare_lane(Lane &L) {
         if (L.ready) return;
