@@ -245,6 +245,67 @@ class ScaleProver:
         return (limbs_to_g1(limbs) if plan.group == _lib.GROUP_G1 else limbs_to_g2(limbs))[0]
 
 
+class ShardedScaleProver(ScaleProver):
+    """The same proof with every MSM sharded over the ranks of a process group by contiguous point chunks (one process
+    per GPU): rank g multiplies its slice of each query by the matching slice of the scalars,
+    the five XYZZ partials travel in ONE all-gather (96 limbs per rank) and are folded in rank order on every rank.  The
+    transforms are cheap next to the MSMs and run replicated.  (A deployment would keep only its slices of the CRS in HBM;
+    here every rank indexes into the full arrays.)"""
+
+    def __init__(self, crs, group=None, device=None):
+        import torch.distributed as dist
+        super().__init__(crs)
+        self.group, self.device = group, device
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def _slice(self, total):
+        from ..distributed import shard_range
+        return shard_range(total, self.rank, self.world)
+
+    def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
+        import torch
+        from ..distributed import all_gather_partials, fold_partials
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        m, W, crs = self.m, self.W, self.crs
+        r, s = r % R, s % R
+        ca, cb, cc, h = self.scratch
+        ua, ub = self.ext_a[:m], self.ext_b1[:m]
+        ua.copy_(d_a)
+        ub.copy_(d_b)
+        self.ext_a[m:] = _dev(_lib.ints_to_limbs([1, r, 0]))
+        self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
+        self.ext_b2[m:] = _dev(_lib.ints_to_limbs([1, s]))
+        for d in (ua, ub, d_c):
+            self.ntt.run(d.data_ptr(), True, None, st)
+        self.ext_b2[:m].copy_(ub)
+
+        def submit(plan, scal, pts, total, point_bytes):
+            lo, hi = self._slice(total)
+            return plan.submit(scal.data_ptr() + 32 * lo, pts.data_ptr() + point_bytes * lo, hi - lo, st)
+
+        t_a = submit(self.g1, self.ext_a, crs.d_s12, m + 3, 64)
+        t_b2 = submit(self.g2, self.ext_b2, crs.d_s22, m + 2, 128)
+        t_b1 = submit(self.g1, self.ext_b1, crs.d_s12, m + 3, 64)
+        t_l = submit(self.g1, d_w, crs.d_s14, W, 64)
+        ca.copy_(ua)
+        cb.copy_(ub)
+        cc.copy_(d_c)
+        for d in (ca, cb, cc):
+            self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
+        fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
+        self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
+        p_a = self.g1.collect_partial(t_a)
+        t_h = submit(self.g1, h, crs.d_s15, m - 1, 64)
+        mine = np.concatenate([p_a, self.g1.collect_partial(t_b1), self.g1.collect_partial(t_l), self.g1.collect_partial(t_h),
+                               self.g2.collect_partial(t_b2)])                       # 4 * 16 + 32 limbs
+        everyone = all_gather_partials(mine, device=self.device, group=self.group)  # (world, 96)
+        g1_parts = [fold_partials(_lib.GROUP_G1, np.ascontiguousarray(everyone[:, 16 * k:16 * (k + 1)])) for k in range(4)]
+        proof_a, msm_b1, msm_l, msm_h = g1_parts
+        proof_b = fold_partials(_lib.GROUP_G2, np.ascontiguousarray(everyone[:, 64:96]))
+        proof_c = msm_g1([s, r, 1, 1], [proof_a, msm_b1, msm_l, msm_h])
+        return proof_a, proof_b, proof_c, h
+
+
 def closed_form_scalars(crs, witness, r, s):
     """(A, B, C) in F_r with proof_A = A*G1, proof_B = B*G2, proof_C = C*G1  (zkp/groth16/test.py:303-325)."""
     t = crs.toxic

@@ -50,3 +50,39 @@ def test_scale_prover_closed_form(log_m):
         q, rem = o.div_polys(P, Z)
         assert all(v == 0 for v in rem)
         assert hc[:len(q)] == q
+
+
+def _sharded_worker(rank, world, port, log_m, ret):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "..", "interactive-zkp-study_amd"))
+    sys.path.insert(0, os.path.join(here, "..", "oracle"))
+    import torch
+    import torch.distributed as dist
+    from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver, ShardedScaleProver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        circ = ChainCircuit(log_m, seed=3)
+        crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 200))
+        w, a, b, c = circ.witness()
+        r, s = 4106, 4565
+        single = ScaleProver(crs).prove(_dev(a), _dev(b), _dev(c), _dev(w), r, s)[:3]
+        sharded = ShardedScaleProver(crs).prove(_dev(a), _dev(b), _dev(c), _dev(w), r, s)[:3]
+        ret[rank] = bool(single == sharded)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prover_equals_single_gpu(world):
+    """Every MSM of the proof sharded over `world` ranks (rehearsed on one GPU over gloo): the proof is identical."""
+    import os
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, port, 10, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
