@@ -149,6 +149,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed priming before the W warm-up steps: after the idle setup phase the GPU needs some tens of ms of load to
+    # reach its sustained clocks; with a small W the first timed steps would otherwise run on a cold clock.
+    run_steps(30)
     if args.warmup:
         run_steps(args.warmup)
     stage = np.zeros(4)

@@ -722,6 +722,15 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         heavy_cap = (uint32_t)(dig_bytes / sizeof(int16_t) / HEAVY_SEG + dig_bytes / sizeof(int16_t) / HEAVY_WAVE + 64);
         nlanes = 3;
         for (int i = 0; i < (all_lanes ? nlanes : 1); i++) prepare_lane(lanes[i]);
+        if (all_lanes) {
+            // Prime every lane with a one-point MSM: the first launches on a new stream pay for the hardware queue and the
+            // code objects (milliseconds), which would otherwise land on the caller's first three submissions.
+            ZK_HIP(hipMemset(lanes[0].arena.p, 0, 128));
+            const bool prof = profile;
+            profile = true;  // creates the profiling events as well
+            for (int i = 0; i < nlanes; i++) (void)collect_lane(submit_lane(lanes[0].arena.p, lanes[0].arena.p, 1, nullptr));
+            profile = prof;
+        }
     }
     void prepare_lane(Lane &L) {
         if (L.ready) return;
