@@ -75,7 +75,10 @@ class DevicePlonk:
         for k in names:
             self.comm[k] = self._commit(self.coef[k], n)
         # identity labels omega^i (times 1, K1, K2 by coefficient) and everything the quotient needs on the coset k*H'
-        ones = _dev(_limbs([1] * n))
+        one = np.zeros((n + PAD, 4), dtype=np.uint64)
+        one[:, 0] = 1
+        self.ones = _dev(one)
+        ones = self.ones[:n].clone()
         self.fv.scale_powers(ones.data_ptr(), n, int(self.omega), self.st)
         self.ident = ones
         self.coset = {k: self._coset(self.coef[k]) for k in names}
@@ -134,10 +137,21 @@ class DevicePlonk:
 
     def _evaluate(self, coef, count, point):
         """p(point) = sum_i c_i point^i (polynomial.py:85-106)."""
-        tmp = coef[:count].clone()
-        self.fv.scale_powers(tmp.data_ptr(), count, int(point), self.st)
-        self.fv.scan(tmp.data_ptr(), count, False, False, self.st)
-        return FR(_lib.limbs_to_ints(tmp[count - 1:count].cpu().numpy().view(np.uint64))[0])
+        return self._evaluate_many([(coef, count)], point)[0]
+
+    def _evaluate_many(self, items, point):
+        """[(coef, count)] -> [p(point)]: the powers of the point are built once, every evaluation is an element-wise
+        product and a running sum, and all values come back in one copy."""
+        cmax = max(c for _, c in items)
+        pw = self.ones[:cmax].clone()
+        self.fv.scale_powers(pw.data_ptr(), cmax, int(point), self.st)
+        res = self._zeros(len(items))
+        tmp = self._zeros(cmax)
+        for k, (coef, count) in enumerate(items):
+            self._mul(tmp, coef, pw, count)
+            self.fv.scan(tmp.data_ptr(), count, False, False, self.st)
+            res[k:k + 1] = tmp[count - 1:count]
+        return [FR(v) for v in _lib.limbs_to_ints(res.cpu().numpy().view(np.uint64))]
 
     def _divide_linear(self, coef, count, point):
         """Quotient of p(x) / (x - point), count - 1 coefficients (the remainder p(point) is dropped)."""
@@ -248,11 +262,8 @@ class DevicePlonk:
 
         # round 4 (round4.py:40-79)
         zeta = tr.challenge_scalar(b"zeta")
-        pr.a_eval = self._evaluate(wires[0], n + 2, zeta)
-        pr.b_eval = self._evaluate(wires[1], n + 2, zeta)
-        pr.c_eval = self._evaluate(wires[2], n + 2, zeta)
-        pr.s_sigma1_eval = self._evaluate(self.coef["s_sigma1"], n, zeta)
-        pr.s_sigma2_eval = self._evaluate(self.coef["s_sigma2"], n, zeta)
+        pr.a_eval, pr.b_eval, pr.c_eval, pr.s_sigma1_eval, pr.s_sigma2_eval = self._evaluate_many(
+            [(wires[0], n + 2), (wires[1], n + 2), (wires[2], n + 2), (self.coef["s_sigma1"], n), (self.coef["s_sigma2"], n)], zeta)
         pr.z_omega_eval = self._evaluate(z, n + 3, zeta * self.omega)
         for name in ("a_eval", "b_eval", "c_eval", "s_sigma1_eval", "s_sigma2_eval", "z_omega_eval"):
             tr.append_scalar(name.encode(), getattr(pr, name))
