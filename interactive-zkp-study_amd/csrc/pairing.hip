@@ -5,7 +5,7 @@
 // Replaces py_ecc.bn128.pairing as the reference uses it: zkp/groth16/verifying.py:17-40,
 // zkp/plonk/field.py:118-138, zkp/plonk/kzg.py:117-160.  The algorithm is py_ecc's
 // (bn128_pairing.py): Miller loop over ate_loop_count = 6u+2 with affine line functions, the two
-// Frobenius correction lines, final exponentiation by (p^12-1)/r -- computed here on the sextic
+// Frobenius correction lines, final exponentiation by (p^12-1)/r (split into its Frobenius-friendly factors, same value) -- computed here on the sextic
 // twist: G2 stays in F_p^2, F_p^12 = F_p^2[w]/(w^6 - xi), xi = 9 + i, and a line through twisted
 // points evaluates to the sparse element  -y_P + (m x_P) w + (y_1 - m x_1) w^3.
 // zk_pairing returns the value in py_ecc's basis (12 coefficients of F_p[w]/(w^12 - 18 w^6 + 82),
@@ -139,9 +139,66 @@ Fp12 miller_loop(const G2Aff &q, const G1Aff &p) {
     return f;
 }
 
+// ---- final exponentiation f^((p^12-1)/r), same value as py_ecc's plain power, computed as
+//   (p^12-1)/r = (p^6-1) (p^2+1) h,   h = (p^4-p^2+1)/r = l0 + l1 p + l2 p^2 + p^3   (base-p digits, bn254_params.h)
+// with the Frobenius maps of F_p^12 = F_p^2[w]/(w^6 - xi):  (c w^k)^p = conj(c) g^k w^k,  g = xi^((p-1)/6).
+struct FrobTable {
+    HFp2 g[6];  // g^k
+    FrobTable() {
+        static const uint32_t c0[8] = ZK_FROB_W_C0, c1[8] = ZK_FROB_W_C1;
+        const HFp2 gw{fp_from_words32(c0), fp_from_words32(c1)};
+        g[0] = HFp2::one();
+        for (int k = 1; k < 6; k++) g[k] = fe_mul(g[k - 1], gw);
+    }
+};
+Fp12 f12_frob(const Fp12 &a) {  // a^p
+    static const FrobTable T;
+    Fp12 r;
+    for (int k = 0; k < 6; k++) r.c[k] = fe_mul(fp2_conj(a.c[k]), T.g[k]);
+    return r;
+}
+Fp12 f12_conj6(const Fp12 &a) {  // a^(p^6): w -> -w
+    Fp12 r = a;
+    for (int k = 1; k < 6; k += 2) r.c[k] = fe_neg(a.c[k]);
+    return r;
+}
+// 1/a: the maps a -> a^(p^2j), j = 1..5, are the F_p^2-automorphisms of F_p^12, so a * prod_j a^(p^2j) is the norm, in F_p^2.
+Fp12 f12_inv(const Fp12 &a) {
+    Fp12 s = f12_frob(f12_frob(a)), g = s;
+    for (int j = 2; j <= 5; j++) {
+        s = f12_frob(f12_frob(s));
+        g = f12_mul(g, s);
+    }
+    const HFp2 ninv = fe_inv(f12_mul(a, g).c[0]);
+    for (auto &x : g.c) x = fe_mul(x, ninv);
+    return g;
+}
+
 Fp12 final_exp(const Fp12 &f) {
-    static const uint64_t e[ZK_FINAL_EXP_WORDS] = ZK_FINAL_EXP;
-    return f12_pow_words(f, e, ZK_FINAL_EXP_WORDS);
+    Fp12 t = f12_mul(f12_conj6(f), f12_inv(f));   // f^(p^6 - 1)
+    t = f12_mul(f12_frob(f12_frob(t)), t);         // ^(p^2 + 1)
+    // t^h by simultaneous square-and-multiply over the three 254-bit digits; the digit of p^3 is 1
+    static const uint64_t L[3][4] = {ZK_HARD_L0, ZK_HARD_L1, ZK_HARD_L2};
+    Fp12 base[3] = {t, f12_frob(t), f12_frob(f12_frob(t))};
+    const Fp12 top = f12_frob(base[2]);
+    Fp12 table[8];  // table[m] = prod_{bit i of m} base[i]
+    table[0] = Fp12::one();
+    for (int m = 1; m < 8; m++) {
+        const int low = m & -m, i = low == 1 ? 0 : low == 2 ? 1 : 2;
+        table[m] = (m == low) ? base[i] : f12_mul(table[m ^ low], base[i]);
+    }
+    Fp12 r = Fp12::one();
+    bool started = false;
+    for (int bit = 255; bit >= 0; bit--) {
+        if (started) r = f12_mul(r, r);
+        const int m = (int)((L[0][bit >> 6] >> (bit & 63)) & 1) | (int)(((L[1][bit >> 6] >> (bit & 63)) & 1) << 1) |
+                      (int)(((L[2][bit >> 6] >> (bit & 63)) & 1) << 2);
+        if (m) {
+            r = started ? f12_mul(r, table[m]) : table[m];
+            started = true;
+        }
+    }
+    return f12_mul(r, top);
 }
 
 G1Aff load_g1(const uint64_t *p) {
