@@ -111,31 +111,89 @@ Fp12 line_and_add(const G2Aff &t1, const G2Aff &t2, const G1Aff &p, G2Aff *sum) 
 
 HFp fp_from_words32(const uint32_t *w) { return fe_to_mont(HFp::from_words(w)); }
 
+// The running point of the Miller loop in homogeneous projective coordinates (x = X/Z, y = Y/Z): no inversion per step.
+// Each line below is the affine line of line_and_add times an F_p^2 factor (2 Y Z resp. x_2 Z - X); factors from the
+// subfield F_p^2 are annihilated by the (p^6 - 1) part of the final exponentiation, so the pairing VALUE is unchanged.
+struct G2Proj {
+    HFp2 x, y, z;
+};
+inline HFp2 fp2_small(unsigned k) { return HFp2{hfe_from_u64<FpTag>(k), HFp::zero()}; }
+
+// tangent at R evaluated at P, R <- 2R.   line * (2 Y Z):  -2 Y Z y_P + 3 X^2 x_P w + (3 b' Z^2 - Y^2) w^3
+Fp12 line_dbl_proj(G2Proj &r, const G1Aff &p, const HFp2 &b3) {
+    const HFp2 xx = fe_sqr(r.x), yy = fe_sqr(r.y), zz = fe_sqr(r.z), s = fe_mul(r.y, r.z);
+    const HFp2 w = fe_add(fe_dbl(xx), xx);                        // 3 X^2
+    Fp12 l;
+    for (auto &c : l.c) c = HFp2::zero();
+    l.c[0] = fe_neg(fp2_mul_fp(fe_dbl(s), p.y));
+    l.c[1] = fp2_mul_fp(w, p.x);
+    l.c[3] = fe_sub(fe_mul(b3, zz), yy);
+    // dbl-1998-cmo-2 (a = 0): B = X Y S, H = W^2 - 8B, X3 = 2 H S, Y3 = W (4B - H) - 8 Y^2 S^2, Z3 = 8 S^3
+    const HFp2 b = fe_mul(fe_mul(r.x, r.y), s);
+    const HFp2 b4 = fe_dbl(fe_dbl(b));
+    const HFp2 h = fe_sub(fe_sqr(w), fe_dbl(b4));
+    const HFp2 ss = fe_sqr(s);
+    const HFp2 yyss8 = fe_dbl(fe_dbl(fe_dbl(fe_mul(yy, ss))));
+    r.x = fe_dbl(fe_mul(h, s));
+    r.y = fe_sub(fe_mul(w, fe_sub(b4, h)), yyss8);
+    r.z = fe_dbl(fe_dbl(fe_dbl(fe_mul(ss, s))));
+    return l;
+}
+// chord through R and the affine point Q evaluated at P, R <- R + Q (R != +-Q, checked by the caller).
+//   line * (x_2 Z - X):  -v y_P + u x_P w + (v y_2 - u x_2) w^3   with u = y_2 Z - Y, v = x_2 Z - X
+Fp12 line_add_proj(G2Proj &r, const G2Aff &q, const G1Aff &p, const HFp2 &u, const HFp2 &v) {
+    Fp12 l;
+    for (auto &c : l.c) c = HFp2::zero();
+    l.c[0] = fe_neg(fp2_mul_fp(v, p.y));
+    l.c[1] = fp2_mul_fp(u, p.x);
+    l.c[3] = fe_sub(fe_mul(v, q.y), fe_mul(u, q.x));
+    // madd-1998-cmo: A = u^2 Z - v^3 - 2 v^2 X, X3 = v A, Y3 = u (v^2 X - A) - v^3 Y, Z3 = v^3 Z
+    const HFp2 vv = fe_sqr(v), vvv = fe_mul(vv, v), rr = fe_mul(vv, r.x);
+    const HFp2 a = fe_sub(fe_sub(fe_mul(fe_sqr(u), r.z), vvv), fe_dbl(rr));
+    const HFp2 y3 = fe_sub(fe_mul(u, fe_sub(rr, a)), fe_mul(vvv, r.y));
+    r.x = fe_mul(v, a);
+    r.y = y3;
+    r.z = fe_mul(vvv, r.z);
+    return l;
+}
+
 Fp12 miller_loop(const G2Aff &q, const G1Aff &p) {
     if (q.inf || p.inf) return Fp12::one();
     static const uint32_t fx0[8] = ZK_FROB_X_C0, fx1[8] = ZK_FROB_X_C1, fy0[8] = ZK_FROB_Y_C0, fy1[8] = ZK_FROB_Y_C1;
     static const HFp2 frob_x{fp_from_words32(fx0), fp_from_words32(fx1)}, frob_y{fp_from_words32(fy0), fp_from_words32(fy1)};
+    static const HFp2 b3 = fe_mul(fp2_small(9), fe_inv(HFp2{hfe_from_u64<FpTag>(9), HFp::one()}));  // 3 b' = 9 / xi
     const uint64_t ate = ZK_ATE_LOOP_LOW64;  // low 64 bits of 6u+2; the 65th bit is the start R = Q
-    G2Aff r = q;
+    G2Proj r{q.x, q.y, HFp2::one()};
     Fp12 f = Fp12::one();
-    for (int i = 63; i >= 0; i--) {
-        G2Aff nr;
-        const Fp12 l = line_and_add(r, r, p, &nr);
-        f = f12_mul(f12_mul(f, f), l);
-        r = nr;
-        if ((ate >> i) & 1) {
-            const Fp12 l2 = line_and_add(r, q, p, &nr);
-            f = f12_mul(f, l2);
-            r = nr;
+    // one chord step; the degenerate positions (R = +-Q, R at infinity) cannot occur for points of prime order inside the
+    // loop, but inputs are not trusted: they go through the affine routine, which handles every case
+    auto add_step = [&](const G2Aff &t) {
+        if (r.z.is_zero()) {  // R = O: the line is 1 up to a subfield factor, R <- T
+            r = G2Proj{t.x, t.y, HFp2::one()};
+            return;
         }
+        const HFp2 u = fe_sub(fe_mul(t.y, r.z), r.y), v = fe_sub(fe_mul(t.x, r.z), r.x);
+        if (v.is_zero()) {
+            const HFp2 zi = fe_inv(r.z);
+            const G2Aff ra{fe_mul(r.x, zi), fe_mul(r.y, zi), false};
+            G2Aff nr;
+            f = f12_mul(f, line_and_add(ra, t, p, &nr));
+            r = nr.inf ? G2Proj{HFp2::zero(), HFp2::one(), HFp2::zero()} : G2Proj{nr.x, nr.y, HFp2::one()};
+            return;
+        }
+        f = f12_mul(f, line_add_proj(r, t, p, u, v));
+    };
+    for (int i = 63; i >= 0; i--) {
+        f = f12_mul(f, f);
+        if (!r.z.is_zero() && !r.y.is_zero()) f = f12_mul(f, line_dbl_proj(r, p, b3));
+        else r = G2Proj{HFp2::zero(), HFp2::one(), HFp2::zero()};
+        if ((ate >> i) & 1) add_step(q);
     }
     // Frobenius images of Q on the twist: pi(x, y) = (conj(x) * xi^((p-1)/3), conj(y) * xi^((p-1)/2))
     G2Aff q1{fe_mul(fp2_conj(q.x), frob_x), fe_mul(fp2_conj(q.y), frob_y), false};
     G2Aff q2{fe_mul(fp2_conj(q1.x), frob_x), fe_neg(fe_mul(fp2_conj(q1.y), frob_y)), false};
-    G2Aff nr;
-    f = f12_mul(f, line_and_add(r, q1, p, &nr));
-    r = nr;
-    f = f12_mul(f, line_and_add(r, q2, p, &nr));
+    add_step(q1);
+    add_step(q2);
     return f;
 }
 
