@@ -124,6 +124,37 @@ def test_ntt_2pow22_bit_exact_vs_oracle():
     assert np.array_equal(d.cpu().numpy().view(np.uint64), co.ntt_arr(X, o.get_root_of_unity(n), False))
 
 
+def test_ntt_maximum_domain_2pow28_round_trip():
+    """The largest domain the reference admits (get_root_of_unity: n <= 2^28, zkp/plonk/field.py:169-172): forward + inverse
+    restores all 2^28 elements, and one output is checked against the closed form of a two-term polynomial."""
+    import torch
+    L = 28
+    n = 1 << L
+    rng = np.random.default_rng(28)
+    base = _fast_rand(rng, 1 << 20)
+    d = torch.from_numpy(base.view(np.int64)).cuda().repeat(n >> 20, 1)       # 8.6 GB on the device, built there
+    ref = d.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    plan = NttPlan(L)
+    plan.run(d.data_ptr(), False, None, st)
+    plan.run(d.data_ptr(), True, None, st)
+    torch.cuda.synchronize()
+    assert torch.equal(d, ref)
+    del ref
+    # x = a + b X^j  ->  y[k] = a + b w^(j k)
+    d.zero_()
+    a, b, j = 12345678901234567890, 987654321987654321, (1 << 27) + 12345
+    d[0:1] = torch.from_numpy(co.to_limbs([a]).view(np.int64)).cuda()
+    d[j:j + 1] = torch.from_numpy(co.to_limbs([b]).view(np.int64)).cuda()
+    plan.run(d.data_ptr(), False, None, st)
+    w = o.get_root_of_unity(n)
+    for k in (0, 1, 77, n // 2 + 5, n - 1):
+        got = co.from_limbs(d[k:k + 1].cpu().numpy().view(np.uint64))[0]
+        assert got == (a + b * pow(w, j * k, o.R)) % o.R, k
+    with pytest.raises(_lib.ZkhipError):
+        NttPlan(29)                                                          # 2^29 is beyond the field's 2-adicity
+
+
 def test_ntt_linearity_2pow18():
     rng = np.random.default_rng(16)
     n = 1 << 18
