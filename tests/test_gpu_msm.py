@@ -353,3 +353,28 @@ def test_chunked_msm_small_chunks(monkeypatch):
     small = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), 3000, st)[0]  # below the chunk size: the ordinary path
     assert np.array_equal(small, co.g1_msm_arr(S[:3000], Pts[:3000]))
     plan.close()
+
+
+def test_g1_msm_2pow24_chunked_closed_form():
+    """BASELINE.json's 2^24 size on one GPU: four 2^22-point chunks through the plan's lanes; P_i = (k0 + i d) G so that the
+    result has the closed form (sum s_i (k0 + i d)) G; a few bases are spot-checked against the oracle."""
+    import torch
+    from bench import random_scalars
+    from helpers import arithmetic_dot, arithmetic_g1_points
+    n = 1 << 24
+    k0, d = 0x1234567890ABCDEF >> 1, 0x9E3779B1
+    lib = _lib.load()
+    Pts = arithmetic_g1_points(lib, n, k0, d)
+    for i in (0, 1, n // 3, n - 1):
+        assert np.array_equal(Pts[i], co.g1_to_arr([co.g1_mul(o.G1, k0 + i * d)])[0])
+    S = random_scalars(np.random.default_rng(24), n)
+    dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    got = plan.run(dS.data_ptr(), dP.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert got == o_point(co.g1_mul(o.G1, arithmetic_dot(S, k0, d)))
+    plan.close()
+
+
+def o_point(pt):
+    from zkhip.field import FQ
+    return None if pt is None else (FQ(pt[0]), FQ(pt[1]))
