@@ -92,6 +92,17 @@ int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_p
  * collected in any order.  An MSM of more than 2^22 points runs as consecutive 2^22-point chunks in
  * those same lanes (partial sums added on the host): it needs all lanes free, zk_msm_submit may block
  * for its early chunks, and it is the only submission outstanding until collected. */
+/* Bound-bases mode.  The bases of a prover's queries never change (CRS / SRS): zk_msm_plan_bind_points expands n device
+ * points once into the plan's table T[w][i] = 2^(20 w) * P_i (13 * n packed points: 832 B per G1 point, 1664 B per G2
+ * point; the plan must have been created for more than 2^17 points, and 13 n < 2^31).  Afterwards every MSM call of the plan
+ * that passes d_points == NULL uses the first n bound bases: one window of 2^19 buckets over the 13 n table entries the
+ * signed 20-bit digits select -- 13 n bucket additions instead of 16 n and a single window to reduce.  n == 0 unbinds.
+ * Results are identical to the unbound calls. */
+int zk_msm_plan_bind_points(zk_msm_plan *plan, const void *d_points, size_t n, void *stream);
+/* Pipelined MSM over the bound bases [first, first + n): several queries (sigma1_2 | sigma1_4 | sigma1_5 ...) can be bound
+ * as one concatenated array and addressed by range; collect with zk_msm_collect / zk_msm_collect_partial.  The bound array
+ * may be longer than the plan's max_n (ranges of more than 2^22 bases run as chunks). */
+int zk_msm_submit_bound(zk_msm_plan *plan, const void *d_scalars, size_t first, size_t n, void *stream, int *out_ticket);
 int zk_msm_plan_max_in_flight(const zk_msm_plan *plan);
 int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket);
 int zk_msm_collect(zk_msm_plan *plan, int ticket, uint64_t *out_xy, int *out_is_inf);

@@ -323,23 +323,36 @@ int zk_msm_plan_stage_ms(const zk_msm_plan *plan, float out_ms[4]) {
     return ZK_OK;
 }
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n) { return plan ? plan->impl->window_bits(n) : ZK_ERR_INVALID; }
+int zk_msm_plan_bind_points(zk_msm_plan *plan, const void *d_points, size_t n, void *stream) {
+    return guarded([&] {
+        if (!plan || (n && !d_points)) return invalid("zk_msm_plan_bind_points: null pointer");
+        return plan->impl->bind_points(d_points, n, (hipStream_t)stream);
+    });
+}
 int zk_msm_plan_max_in_flight(const zk_msm_plan *plan) { return plan ? plan->impl->max_in_flight() : ZK_ERR_INVALID; }
 int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, void *stream) {
     return guarded([&] {
-        if (!plan || !out_xy || (n && (!d_scalars || !d_points))) return invalid("zk_msm_dev: null pointer");
+        if (!plan || !out_xy || (n && !d_scalars)) return invalid("zk_msm_dev: null pointer");
         return plan->impl->run_affine(d_scalars, d_points, n, out_xy, out_is_inf, (hipStream_t)stream);
     });
 }
 int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, void *stream) {
     return guarded([&] {
-        if (!plan || !out_xyzz || (n && (!d_scalars || !d_points))) return invalid("zk_msm_dev_partial: null pointer");
+        if (!plan || !out_xyzz || (n && !d_scalars)) return invalid("zk_msm_dev_partial: null pointer");
         return plan->impl->run_partial(d_scalars, d_points, n, out_xyzz, (hipStream_t)stream);
     });
 }
 int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket) {
     return guarded([&] {
-        if (!plan || !out_ticket || (n && (!d_scalars || !d_points))) return invalid("zk_msm_submit: null pointer");
+        if (!plan || !out_ticket || (n && !d_scalars)) return invalid("zk_msm_submit: null pointer");
         *out_ticket = plan->impl->submit(d_scalars, d_points, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
+int zk_msm_submit_bound(zk_msm_plan *plan, const void *d_scalars, size_t first, size_t n, void *stream, int *out_ticket) {
+    return guarded([&] {
+        if (!plan || !out_ticket || (n && !d_scalars)) return invalid("zk_msm_submit_bound: null pointer");
+        *out_ticket = plan->impl->submit_bound(d_scalars, first, n, (hipStream_t)stream);
         return ZK_OK;
     });
 }

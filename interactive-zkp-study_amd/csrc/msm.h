@@ -20,6 +20,9 @@ struct MsmPlanBase {
     virtual int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) = 0;
     virtual int collect_affine(int ticket, uint64_t *out_xy, int *out_is_inf) = 0;
     virtual int collect_partial(int ticket, uint64_t *out_xyzz) = 0;
+    // bound-bases mode: expand the points into the plan's table (n == 0 unbinds); afterwards d_points == nullptr selects it
+    virtual int bind_points(const void *d_points, size_t n, hipStream_t st) = 0;
+    virtual int submit_bound(const void *d_scalars, size_t first, size_t n, hipStream_t st) = 0;
 };
 // all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use
 MsmPlanBase *msm_plan_new_g1(size_t max_n, bool all_lanes);

@@ -1,0 +1,148 @@
+// msm_fixed.h -- bound-bases mode of the MSM plan: the points of a prover's queries never change (CRS / SRS), so
+// they are expanded ONCE into a table  T[w][i] = 2^(20 w) * P_i  (13 rows; 288 GB of HBM make 832 B per point cheap).
+// Every signed 20-bit digit d_{i,w} of a scalar then selects the table entry (w, i) for ONE window of 2^19 buckets:
+//   sum_i k_i P_i = sum_{i,w} d_{i,w} T[w][i]
+// -- 13 n bucket additions instead of the 16 n of sixteen 16-bit windows (-19 %), the same 2^19 buckets to reduce, and
+// a single window for the host fold.  The kernels after the partition (cell sort, rank, accumulate, heavy buckets,
+// reduce) are the generic ones of msm_impl.h run with W = 1, nb = 2^19; this header adds the table builder, the digit
+// kernel and a partition kernel for 2048 cells per window.
+#pragma once
+#include "msm_impl.h"
+
+namespace zk {
+
+constexpr int FIX_C = 20;
+constexpr int FIX_W = (255 + FIX_C - 1) / FIX_C;                   // 13
+constexpr uint32_t FIX_NB = 1u << (FIX_C - 1);                     // 2^19 buckets
+constexpr uint32_t FIX_G = FIX_NB / SEG_BUCKETS;                   // 2048 cells
+static_assert(FIX_G <= MAX_CELLS, "the one window's cells must fit the scan kernel");
+
+// table[w * stride + i] = 2^(20 w) * P_i as a packed Montgomery affine point (infinity stays the all-zero encoding).
+template <class F>
+__global__ __launch_bounds__(64) void msm_fixed_table_kernel(const uint32_t *__restrict__ points, PackedAffine<F> *__restrict__ table, uint32_t n,
+                                                             size_t stride) {
+    constexpr int PW = F::CANON_WORDS;
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const F x = ld_canonical<F>(points + (size_t)i * 2 * PW), y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
+    Affine<F> a = (x.is_zero() && y.is_zero()) ? Affine<F>::inf() : Affine<F>{fe_to_mont(x), fe_to_mont(y)};
+#pragma unroll 1
+    for (int w = 0; w < FIX_W; w++) {
+        table[(size_t)w * stride + i] = pack_affine(Affine<F>{fe_reduce_full(a.x), fe_reduce_full(a.y)});
+        if (w + 1 == FIX_W) break;
+        Xyzz<F> q = Xyzz<F>::from_affine(a);
+#pragma unroll 1
+        for (int k = 0; k < FIX_C; k++) q = xyzz_dbl(q);
+        a = xyzz_to_affine(q);
+    }
+}
+
+// digits[w * n_pad + i] = signed 20-bit digit w of scalar i (int32); cell_total[g] += digits whose bucket lies in cell g.
+template <int DUMMY>
+__global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32_t *__restrict__ scalars, int32_t *__restrict__ digits,
+                                                                   uint32_t *__restrict__ cell_total, uint32_t n, uint32_t n_pad) {
+    constexpr int C = FIX_C, W = FIX_W;
+    __shared__ uint32_t hist[FIX_G];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t; k < FIX_G; k += PREP_NT) hist[k] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int rep = 0; rep < PREP_PPT; rep++) {
+        const uint32_t i = (blockIdx.x * PREP_PPT + rep) * PREP_NT + t;
+        if (i >= n) {
+#pragma unroll
+            for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
+            continue;
+        }
+        uint32_t s[8];
+        ld_words<8>(scalars + (size_t)i * 8, s);
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            constexpr uint32_t mask = (1u << C) - 1u;
+            const int off = w * C, word = off >> 5, sh = off & 31;
+            uint32_t raw = 0;
+            if (word < 8) {
+                raw = s[word] >> sh;
+                if (sh + C > 32 && word + 1 < 8) raw |= s[word + 1] << (32 - sh);
+            }
+            raw &= mask;
+            const uint32_t v = raw + carry;
+            int d;
+            if (v >= (1u << (C - 1))) {
+                d = (int)v - (1 << C);
+                carry = 1;
+            } else {
+                d = (int)v;
+                carry = 0;
+            }
+            digits[(size_t)w * n_pad + i] = d;
+            if (d != 0) atomicAdd(&hist[((uint32_t)(d < 0 ? -d : d) - 1u) >> SEG_LOG], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < FIX_G; k += PREP_NT) {
+        const uint32_t h = hist[k];
+        if (h) atomicAdd(&cell_total[k], h);
+    }
+}
+
+// One workgroup = 4096 consecutive (window, point) entries of the flat digit array (all of one window row: n_pad is a
+// multiple of 4096).  Ranks them by cell in LDS, reserves the cells' spans and writes the entries out cell by cell;
+// the stored index is the TABLE row  w * stride + first + i  (| sign << 31), so the generic accumulate kernel gathers
+// straight from the table.
+template <int DUMMY>
+__global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int32_t *__restrict__ digits, SortBufs B, uint32_t n_pad, size_t stride,
+                                                                     uint32_t first) {
+    constexpr int NE = PREP_NT * PREP_PPT;
+    __shared__ uint32_t hist[FIX_G];   // counts, then exclusive offsets
+    __shared__ uint32_t gpos[FIX_G];
+    __shared__ uint32_t wave_tot[PREP_NT / 64 + 1];
+    __shared__ uint32_t stage_idx[NE];
+    __shared__ uint16_t stage_cell[NE];
+    __shared__ uint8_t stage_loc[NE];
+    const uint32_t t = threadIdx.x;
+    const size_t v0 = (size_t)blockIdx.x * NE;
+    const uint32_t w = (uint32_t)(v0 / n_pad), i0 = (uint32_t)(v0 % n_pad);
+    for (uint32_t k = t; k < FIX_G; k += PREP_NT) hist[k] = 0;
+    __syncthreads();
+    uint32_t rk[PREP_PPT], jj[PREP_PPT];
+    int dd[PREP_PPT];
+#pragma unroll
+    for (int rep = 0; rep < PREP_PPT; rep++) {
+        dd[rep] = digits[v0 + t + rep * PREP_NT];
+        jj[rep] = (uint32_t)(dd[rep] < 0 ? -dd[rep] : dd[rep]) - 1u;
+        rk[rep] = dd[rep] != 0 ? atomicAdd(&hist[jj[rep] >> SEG_LOG], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 cell counts: two per thread
+    static_assert(FIX_G == 2 * PREP_NT, "two cells per thread");
+    const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<PREP_NT>(h0 + h1, wave_tot, &total);
+    hist[2 * t] = ex;
+    hist[2 * t + 1] = ex + h0;
+    gpos[2 * t] = h0 ? B.cell_base[2 * t] + atomicAdd(&B.cell_cursor[2 * t], h0) : 0u;
+    gpos[2 * t + 1] = h1 ? B.cell_base[2 * t + 1] + atomicAdd(&B.cell_cursor[2 * t + 1], h1) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < PREP_PPT; rep++) {
+        if (dd[rep] != 0) {
+            const uint32_t cellg = jj[rep] >> SEG_LOG;
+            const uint32_t p = hist[cellg] + rk[rep];
+            const size_t row = (size_t)w * stride + first + i0 + t + rep * PREP_NT;
+            stage_idx[p] = (uint32_t)row | (dd[rep] < 0 ? 0x80000000u : 0u);
+            stage_loc[p] = (uint8_t)(jj[rep] & (SEG_BUCKETS - 1));
+            stage_cell[p] = (uint16_t)cellg;
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < total; p += PREP_NT) {
+        const uint32_t cellg = stage_cell[p];
+        const uint32_t dst = gpos[cellg] + (p - hist[cellg]);
+        B.e_idx[dst] = stage_idx[p];
+        B.e_loc[dst] = stage_loc[p];
+    }
+}
+
+}  // namespace zk

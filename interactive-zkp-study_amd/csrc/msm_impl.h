@@ -650,6 +650,43 @@ __global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz
     if (t <= levels) out[(size_t)blockIdx.x * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
 }
 
+// The same upper-tree step as one launch per step, spread over many workgroups (grid.x covers the tasks, grid.y the
+// windows): for windows with many blocks (the 2^19-bucket window of the bound-bases mode has 1024) a single workgroup
+// per window would run tens of dependent addition rounds.  The last step's launch also writes out[].
+template <class F>
+__global__ __launch_bounds__(256) void msm_reduce_window_step_kernel(Xyzz<F> *x, Xyzz<F> *__restrict__ out, uint32_t nb, uint32_t BL, uint32_t levels,
+                                                                     uint32_t s, uint32_t write_out) {
+    Xyzz<F> *win = x + (size_t)blockIdx.y * nb;
+    const uint32_t UL = levels - BL;
+    if (!write_out) {
+        const uint32_t sh = UL - 1 - s, per = 1u << sh;
+        const uint32_t ntasks = (s + 1 + BL) * per;
+        const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+        if (q >= ntasks) return;
+        const uint32_t grp = q >> sh, i = q & (per - 1u);
+        uint32_t dst, src;
+        if (grp == s) {
+            dst = (i << (s + 1)) << BL;
+            src = dst + ((1u << s) << BL);
+        } else if (grp < s) {
+            const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
+            dst = ((2 * j + 1) << l) << BL;
+            src = ((2 * (j + (1u << k)) + 1) << l) << BL;
+        } else {
+            const uint32_t l = grp - s - 1;
+            dst = ((i << (s + 1)) << BL) + (1u << l);
+            src = dst + ((1u << s) << BL);
+        }
+        Xyzz<F> a = win[dst];
+        const Xyzz<F> b = win[src];
+        xyzz_add(a, b);
+        win[dst] = a;
+    } else {
+        const uint32_t t = threadIdx.x;
+        if (blockIdx.x == 0 && t <= levels) out[(size_t)blockIdx.y * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 static int pick_window_bits(size_t n) {
     // Measured on MI355X (blocking and pipelined, n = 2^2 .. 2^19): below ~2^9 points everything is launch latency and the
@@ -662,6 +699,11 @@ static int pick_window_bits(size_t n) {
     return 16;
 }
 
+}  // namespace zk
+#define ZK_MSM_IMPL_KERNELS_DONE
+#include "msm_fixed.h"
+namespace zk {
+
 template <class F> struct MsmPlanImpl : MsmPlanBase {
     typedef typename HostOf<F>::type HF;
     size_t max_n;
@@ -673,17 +715,21 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // tail leave CUs idle that the neighbouring MSM's accumulate kernel fills (2^20 points: 1.89 -> 1.73 ms per
     // MSM with three lanes).  Lanes beyond the first are allocated on first use.
     struct Lane {
+        DevBuf digits32;  // bound-bases mode: 13 signed 20-bit digits per scalar as int32, allocated on first use
         DevBuf pts_m, digits, sorted, e_idx, e_loc, counts, bucket_off, cells, zcount, size_bins, perm, arena, out, heavy_tasks, heavy_buckets,
             heavy_partial;
         PinnedBuf h_out;
         hipStream_t stream = nullptr;
         hipEvent_t ev_in = nullptr, ev_consumed = nullptr, done = nullptr;
         hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling; [5], [6] bracket the accumulate kernel
-        bool ready = false, busy = false, empty = false, profiled = false;
+        bool ready = false, busy = false, empty = false, profiled = false, single_window = false;
         int c = 0;
     };
     static constexpr int MAX_LANES = 3;
     Lane lanes[MAX_LANES];
+    // bound bases (msm_fixed.h): table[w * fix_n + i] = 2^(20 w) * P_i, shared by the lanes
+    DevBuf fix_table;
+    size_t fix_n = 0;
     int nlanes = 1, next_lane = 0;
 
     // MSMs beyond 2^22 points are run as consecutive chunks of 2^22 (each in its own lane, partial sums added on the
@@ -784,10 +830,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, L.stream, sc, pt,
                            L.pts_m.template as<PackedAffine<F>>(), L.digits.template as<int16_t>(), L.cells.template as<uint32_t>(), n, n_pad);
     }
-    void launch_sort_accumulate(Lane &L, uint32_t n_pad, uint32_t nb, uint32_t W) {
-        hipStream_t st = L.stream;
-        const uint32_t G = (nb + SEG_BUCKETS - 1) / SEG_BUCKETS;
-        if (G * W > MAX_CELLS) throw std::runtime_error("zk_msm: too many sort cells");
+    SortBufs sort_bufs(Lane &L) {
         SortBufs B;
         B.counts = L.counts.template as<uint32_t>();
         B.bucket_off = L.bucket_off.template as<uint32_t>();
@@ -803,11 +846,19 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.size_base = B.size_hist + SIZE_BINS;
         B.size_cursor = B.size_hist + 2 * SIZE_BINS;
         B.perm = L.perm.template as<uint32_t>();
-        B.heavy_th = std::max<uint32_t>(32, 8 * (n_pad / nb));
+        B.heavy_th = 32;
         B.heavy_cap = heavy_cap;
         B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
         B.heavy_tasks = L.heavy_tasks.template as<uint2>();
         B.heavy_buckets = L.heavy_buckets.template as<uint4>();
+        return B;
+    }
+    void launch_sort_accumulate(Lane &L, uint32_t n_pad, uint32_t nb, uint32_t W) {
+        hipStream_t st = L.stream;
+        const uint32_t G = (nb + SEG_BUCKETS - 1) / SEG_BUCKETS;
+        if (G * W > MAX_CELLS) throw std::runtime_error("zk_msm: too many sort cells");
+        SortBufs B = sort_bufs(L);
+        B.heavy_th = std::max<uint32_t>(32, 8 * (n_pad / nb));
         const uint32_t nbuckets_all = W * nb;
         hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B, n_pad, W,
@@ -836,14 +887,104 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // stream: it starts once everything queued on `st` so far has finished, and `st` resumes as soon as the prepare
     // kernel has consumed the caller's scalars and points (the only kernel that reads them).
     int submit(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) override {
+        if (!d_points && n) return submit_bound(d_scalars, 0, n, st);
         if (n > max_n) throw std::runtime_error("zk_msm: n exceeds the plan's max_n");
         if (big.active) throw std::runtime_error("zk_msm: a chunked (> 2^22 points) submission is outstanding; collect it first");
-        if (n > cap_n) return submit_chunked(d_scalars, d_points, n, st);
+        if (n > cap_n) return submit_chunked(d_scalars, d_points, 0, n, st);
         return submit_lane(d_scalars, d_points, n, st);
+    }
+    // MSM over the bound bases [first, first + n)
+    int submit_bound(const void *d_scalars, size_t first, size_t n, hipStream_t st) override {
+        if (!fix_n) throw std::runtime_error("zk_msm: no bases bound (zk_msm_plan_bind_points)");
+        if (first + n > fix_n) throw std::runtime_error("zk_msm: range exceeds the bound bases");
+        if (big.active) throw std::runtime_error("zk_msm: a chunked (> 2^22 points) submission is outstanding; collect it first");
+        if (n == 0) return submit_lane(d_scalars, nullptr, 0, st);
+        if (n > cap_n) return submit_chunked(d_scalars, nullptr, first, n, st);
+        return submit_lane_fixed(d_scalars, first, n, st);
+    }
+
+    // ---- bound-bases mode (msm_fixed.h)
+    int bind_points(const void *d_points, size_t n, hipStream_t st) override {
+        if (n == 0) {
+            fix_n = 0;
+            fix_table.release();
+            return ZK_OK;
+        }
+        if (pick_window_bits(cap_n) != 16) throw std::runtime_error("zk_msm_plan_bind_points: the plan must be created for more than 2^17 points");
+        if ((uint64_t)FIX_W * n >= ((uint64_t)1 << 31)) throw std::runtime_error("zk_msm_plan_bind_points: too many bases (13 n must stay below 2^31)");
+        for (int i = 0; i < nlanes; i++)
+            if (lanes[i].busy) throw std::runtime_error("zk_msm_plan_bind_points: submissions outstanding");
+        fix_n = 0;
+        fix_table.alloc((size_t)FIX_W * n * sizeof(PackedAffine<F>));
+        hipLaunchKernelGGL((msm_fixed_table_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, static_cast<const uint32_t *>(d_points),
+                           fix_table.template as<PackedAffine<F>>(), (uint32_t)n, n);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));
+        fix_n = n;
+        return ZK_OK;
+    }
+    int submit_lane_fixed(const void *d_scalars, size_t first, size_t n, hipStream_t st) {
+        const int ticket = next_lane;
+        Lane &L = lanes[ticket];
+        if (L.busy) throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect the oldest first");
+        prepare_lane(L);
+        const uint32_t n_pad = (uint32_t)pad_n(n);
+        if (L.digits32.bytes < (size_t)FIX_W * pad_n(cap_n) * sizeof(int32_t)) L.digits32.alloc((size_t)FIX_W * pad_n(cap_n) * sizeof(int32_t));
+        L.busy = true;
+        L.empty = false;
+        L.profiled = profile;
+        L.single_window = true;
+        L.c = FIX_C;
+        next_lane = (next_lane + 1) % nlanes;
+        hipStream_t ls = L.stream;
+        ZK_HIP(hipEventRecord(L.ev_in, st));
+        ZK_HIP(hipStreamWaitEvent(ls, L.ev_in, 0));
+        mark(L, 0);
+        hipLaunchKernelGGL((msm_fixed_prepare_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, ls, static_cast<const uint32_t *>(d_scalars),
+                           L.digits32.template as<int32_t>(), L.cells.template as<uint32_t>(), (uint32_t)n, n_pad);
+        ZK_HIP(hipEventRecord(L.ev_consumed, ls));
+        ZK_HIP(hipStreamWaitEvent(st, L.ev_consumed, 0));
+        mark(L, 1);
+        SortBufs B = sort_bufs(L);
+        B.heavy_th = std::max<uint32_t>(32, 8 * (uint32_t)(((size_t)FIX_W * n_pad) / FIX_NB));
+        const PackedAffine<F> *table = fix_table.template as<PackedAffine<F>>();
+        hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
+        hipLaunchKernelGGL((msm_fixed_partition_kernel<0>), dim3((unsigned)(((size_t)FIX_W * n_pad) / (PREP_NT * PREP_PPT))), dim3(PREP_NT), 0, ls,
+                           L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first);
+        hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B);
+        hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B, FIX_NB);
+        hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
+        hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((FIX_NB + 2047) / 2048), dim3(1024), 0, ls, B, FIX_NB);
+        mark(L, 2);
+        mark(L, 5);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((FIX_NB + 63) / 64), dim3(64), 0, ls, table, L.sorted.template as<uint32_t>(),
+                           L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(), L.perm.template as<uint32_t>(),
+                           L.arena.template as<Xyzz<F>>(), FIX_NB, B.heavy_th);
+        mark(L, 6);
+        hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, ls, B);
+        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, ls, table, B,
+                           L.heavy_partial.template as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, ls, B, L.heavy_partial.template as<Xyzz<F>>(),
+                           L.arena.template as<Xyzz<F>>());
+        mark(L, 3);
+        const uint32_t levels = FIX_C - 1, BL = 9;
+        hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3(FIX_NB >> BL), dim3(1u << (BL - 1)), 0, ls, L.arena.template as<Xyzz<F>>(), BL);
+        for (uint32_t step = 0; step < levels - BL; step++) {
+            const uint32_t ntasks = (step + 1 + BL) << (levels - BL - 1 - step);
+            hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3((ntasks + 255) / 256, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(),
+                               L.out.template as<Xyzz<F>>(), FIX_NB, BL, levels, step, 0u);
+        }
+        hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3(1, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(), L.out.template as<Xyzz<F>>(),
+                           FIX_NB, BL, levels, 0u, 1u);
+        mark(L, 4);
+        ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, (size_t)(levels + 1) * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, ls));
+        ZK_HIP(hipEventRecord(L.done, ls));
+        ZK_HIP(hipGetLastError());
+        return ticket;
     }
     // n > CHUNK: every chunk is an ordinary submission; when the lanes run out the oldest chunk is collected (this call
     // then blocks for it).  The ticket stands for the whole MSM; no other submission may be outstanding meanwhile.
-    int submit_chunked(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
+    int submit_chunked(const void *d_scalars, const void *d_points, size_t first, size_t n, hipStream_t st) {
         for (int i = 0; i < nlanes; i++)
             if (lanes[i].busy) throw std::runtime_error("zk_msm: an MSM of more than 2^22 points needs all lanes free; collect first");
         big.active = true;
@@ -857,7 +998,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                 for (int i = 1; i < big.npend; i++) big.pend[i - 1] = big.pend[i];
                 big.npend--;
             }
-            big.pend[big.npend++] = submit_lane(sc + off * 8, pt + off * 2 * F::CANON_WORDS, m, st);
+            big.pend[big.npend++] = d_points ? submit_lane(sc + off * 8, pt + off * 2 * F::CANON_WORDS, m, st) : submit_lane_fixed(sc + off * 8, first + off, m, st);
         }
         return BIG_TICKET;
     }
@@ -869,6 +1010,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.busy = true;
         L.empty = (n == 0);
         L.profiled = profile;
+        L.single_window = false;
         next_lane = (next_lane + 1) % nlanes;
         if (n == 0) return ticket;
         const int c = pick_window_bits(n);
@@ -927,7 +1069,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             ZK_HIP(hipEventElapsedTime(&stage_ms[3], L.ev[3], L.ev[4]));
         }
         const int c = L.c;
-        const uint32_t W = (255 + c - 1) / c, levels = c - 1;
+        const uint32_t W = L.single_window ? 1u : (uint32_t)((255 + c - 1) / c), levels = c - 1;
         // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
         const Xyzz<F> *h = L.h_out.template as<Xyzz<F>>();
         auto conv = [](const Xyzz<F> &p) { return Xyzz<HF>{HF::from_dev(p.x), HF::from_dev(p.y), HF::from_dev(p.zz), HF::from_dev(p.zzz)}; };

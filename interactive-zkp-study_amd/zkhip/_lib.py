@@ -42,6 +42,8 @@ _PROTOS = {
     "zk_msm_plan_destroy": (ctypes.c_int, [_VP]),
     "zk_msm_plan_window_bits": (ctypes.c_int, [_VP, _SZ]),
     "zk_msm_plan_max_in_flight": (ctypes.c_int, [_VP]),
+    "zk_msm_plan_bind_points": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
+    "zk_msm_submit_bound": (ctypes.c_int, [_VP, _VP, _SZ, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
     "zk_msm_plan_profile": (ctypes.c_int, [_VP, ctypes.c_int]),
     "zk_msm_plan_stage_ms": (ctypes.c_int, [_VP, ctypes.POINTER(ctypes.c_float)]),
     "zk_msm_dev": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int), _VP]),

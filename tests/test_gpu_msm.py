@@ -378,3 +378,59 @@ def test_g1_msm_2pow24_chunked_closed_form():
 def o_point(pt):
     from zkhip.field import FQ
     return None if pt is None else (FQ(pt[0]), FQ(pt[1]))
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_bound_bases_mode_equals_unbound(group, monkeypatch):
+    """zk_msm_plan_bind_points: the 13-row table of 2^(20 w) * P_i and one window of 2^19 buckets must give the very same
+    points as the ordinary 16-window path -- uniform and skewed scalars, prefixes of the bound bases, infinity among the
+    bases, three submissions in flight, and a chunked call (test knob) that walks the table with an offset."""
+    import torch
+    monkeypatch.setenv("ZK_MSM_CHUNK_LOG", "18")                     # plan workspace for 2^18 points: chunking at testable sizes
+    rng = np.random.default_rng(41)
+    g2 = group == "g2"
+    n = (1 << 18) + 5000 if not g2 else 9000
+    if g2:
+        base, _ = rand_g2_limbs(rng, 32)
+        Pts = base[rng.integers(0, 32, size=n)]
+    else:
+        from helpers import arithmetic_g1_points
+        Pts = arithmetic_g1_points(_lib.load(), n, 0x1234567890ABCDEF >> 1, 0x9E3779B1)
+    Pts[7] = 0                                                        # an infinity base
+    from bench import random_scalars
+    S = random_scalars(rng, n)
+    S[3] = 0
+    S[4] = limb_row(o.R - 1)
+    W = S.copy()
+    pick = rng.random(n)
+    W[pick < 0.3] = limb_row(1)
+    W[(pick >= 0.3) & (pick < 0.5)] = 0
+    dP = torch.from_numpy(Pts.view(np.int64)).cuda()
+    dS, dW = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(W.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, 1 << 18)   # max_n 2^18: n above it only through chunks... use a second plan
+    plan.close()
+    plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, max(n, (1 << 17) + 1))
+    want_s = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), n, st)
+    want_w = plan.run_limbs(dW.data_ptr(), dP.data_ptr(), n, st)
+    want_pre = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), 5001, st)
+    with pytest.raises(_lib.ZkhipError):
+        plan.run_limbs(dS.data_ptr(), None, n, st)                    # nothing bound yet
+    plan.bind(dP.data_ptr(), n, st)
+    for _ in range(2):
+        got = plan.run_limbs(dS.data_ptr(), None, n, st)
+        assert np.array_equal(got[0], want_s[0]) and got[1] == want_s[1]
+    got = plan.run_limbs(dW.data_ptr(), None, n, st)
+    assert np.array_equal(got[0], want_w[0])
+    got = plan.run_limbs(dS.data_ptr(), None, 5001, st)               # a prefix of the bound bases
+    assert np.array_equal(got[0], want_pre[0])
+    if n <= (1 << 18):                                                # unchunked sizes: keep three in flight, mixed with unbound calls
+        t = [plan.submit(dS.data_ptr(), None, n, st), plan.submit(dW.data_ptr(), dP.data_ptr(), n, st), plan.submit(dW.data_ptr(), None, n, st)]
+        r = [plan.collect_limbs(x) for x in t]
+        assert np.array_equal(r[0][0], want_s[0]) and np.array_equal(r[1][0], want_w[0]) and np.array_equal(r[2][0], want_w[0])
+    with pytest.raises(_lib.ZkhipError):
+        plan.run_limbs(dS.data_ptr(), None, n + 1, st)                # more than bound
+    plan.bind(None, 0, st)                                            # unbind
+    with pytest.raises(_lib.ZkhipError):
+        plan.run_limbs(dS.data_ptr(), None, n, st)
+    plan.close()
