@@ -223,6 +223,34 @@ def main():
         else:
             extra["sharded_one_msm"] = {"error": "setup failed on some rank"}
 
+    # ---- secondary: the same MSM with the bases bound to the plan (zk_msm_plan_bind_points: what a prover does with its
+    # CRS / SRS); the one-off table build is outside the timed loop, as a prover's key loading is
+    if rank == 0 and world == 1 and n > (1 << 17):
+        tb0 = time.perf_counter()
+        plan.bind(d_points.data_ptr(), n, stream)
+        bind_s = time.perf_counter() - tb0
+        pend, bres = [], None
+        for _ in range(10):
+            pend.append(plan.submit(d_scalars.data_ptr(), None, n, stream))
+            if len(pend) == depth:
+                bres = plan.collect_limbs(pend.pop(0))
+        for t in pend:
+            bres = plan.collect_limbs(t)
+        pend = []
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        bsteps = 60
+        for _ in range(bsteps):
+            pend.append(plan.submit(d_scalars.data_ptr(), None, n, stream))
+            if len(pend) == depth:
+                bres = plan.collect_limbs(pend.pop(0))
+        for t in pend:
+            bres = plan.collect_limbs(t)
+        bms = (time.perf_counter() - tb0) / bsteps * 1e3
+        extra["bound_bases"] = {"ms_per_step": round(bms, 4), "points_per_s": n / (bms * 1e-3), "bind_ms": round(bind_s * 1e3, 1),
+                                "table_bytes": 13 * n * 64, "same_result_as_unbound": bool(np.array_equal(bres[0], result[0]) and bres[1] == result[1])}
+        plan.bind(None, 0, stream)
+
     # ---- secondary: NTT forward + inverse round trip (BASELINE.json configs[2]).  With N > 1 every rank transforms a
     # polynomial of its own (batch-parallel mode: no exchange) between barriers; the aggregate is N transforms per span.
     if args.ntt_log_n:
