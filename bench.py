@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048, help="points timed on the pure-Python baseline (0 = skip)")
     ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
     ap.add_argument("--plonk-log-n", type=int, default=20, help="log2 gates of the secondary device-resident PLONK prove() timing (0 = skip)")
+    ap.add_argument("--no-bound", action="store_true", help="skip the secondary bound-bases run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--shard-total-log", type=int, default=26, help="N > 1 only: log2 points of the secondary ONE-MSM-sharded-over-all-GPUs "
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
@@ -225,7 +226,7 @@ def main():
 
     # ---- secondary: the same MSM with the bases bound to the plan (zk_msm_plan_bind_points: what a prover does with its
     # CRS / SRS); the one-off table build is outside the timed loop, as a prover's key loading is
-    if rank == 0 and world == 1 and n > (1 << 17):
+    if rank == 0 and world == 1 and n > (1 << 17) and not args.no_bound:
         tb0 = time.perf_counter()
         plan.bind(d_points.data_ptr(), n, stream)
         bind_s = time.perf_counter() - tb0
