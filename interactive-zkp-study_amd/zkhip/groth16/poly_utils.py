@@ -10,22 +10,21 @@ from ..field import FR
 
 
 def _multiply_polys(a, b):
-    """poly_utils.py:17-22"""
-    o = [0] * (len(a) + len(b) - 1)
-    for i in range(len(a)):
-        for j in range(len(b)):
-            o[i + j] += a[i] * b[j]
-    return o
+    """Coefficient convolution (poly_utils.py:17-22)."""
+    out = [0] * (len(a) + len(b) - 1)
+    for shift, coeff in enumerate(a):
+        for k, other in enumerate(b, start=shift):
+            out[k] += coeff * other
+    return out
 
 
 def _add_polys(a, b, subtract=False):
-    """poly_utils.py:25-31"""
-    o = [0] * max(len(a), len(b))
-    for i in range(len(a)):
-        o[i] += a[i]
-    for i in range(len(b)):
-        o[i] += b[i] * (-1 if subtract else 1)
-    return o
+    """Coefficient-wise a + b, or a - b with subtract=True (poly_utils.py:25-31); the shorter operand is zero-extended."""
+    sign = -1 if subtract else 1
+    longer = max(len(a), len(b))
+    left = list(a) + [0] * (longer - len(a))
+    right = list(b) + [0] * (longer - len(b))
+    return [x + sign * y for x, y in zip(left, right)]
 
 
 def _subtract_polys(a, b):
@@ -33,38 +32,48 @@ def _subtract_polys(a, b):
 
 
 def _div_polys(a, b):
-    """poly_utils.py:37-45: long division, returns (quotient, remainder)."""
-    o = [0] * (len(a) - len(b) + 1)
-    remainder = a
-    while len(remainder) >= len(b):
-        leading_fac = remainder[-1] / b[-1]
-        pos = len(remainder) - len(b)
-        o[pos] = leading_fac
-        remainder = _subtract_polys(remainder, _multiply_polys(b, [0] * pos + [leading_fac]))[:-1]
-    return o, remainder
+    """Schoolbook long division a = q * b + rem (poly_utils.py:37-45) -> (q, rem); rem keeps len(b) - 1 coefficients.
+    Works on the reference's element types (FR, or plain numbers with true division)."""
+    rem = list(a)
+    top = len(b) - 1
+    quot = [0] * (len(a) - top)
+    for pos in range(len(quot) - 1, -1, -1):
+        factor = rem[pos + top] / b[top]
+        quot[pos] = factor
+        for k, coeff in enumerate(b):
+            rem[pos + k] = rem[pos + k] - factor * coeff
+        rem.pop()
+    return quot, rem
 
 
 def _eval_poly(poly, x):
-    """poly_utils.py:48-49"""
-    return sum([poly[i] * x ** i for i in range(len(poly))])
+    """poly(x) by Horner's rule (same value as the power sum of poly_utils.py:48-49)."""
+    acc = 0
+    for coeff in reversed(poly):
+        acc = acc * x + coeff
+    return acc
 
 
 def _multiply_vec_matrix(vec, matrix):
-    """poly_utils.py:52-59 (result has len(vec) entries; asserts W != G like the reference)."""
-    assert not len(vec) == len(matrix[0])
-    target = [FR(0)] * len(vec)
-    for i in range(len(matrix)):
-        for j in range(len(matrix[0])):
-            target[j] = target[j] + vec[i] * matrix[i][j]
-    return target
+    """vec . matrix (poly_utils.py:52-59).  Kept as the reference has it: the result carries len(vec) entries, of which
+    only the first len(matrix[0]) are ever written, and square shapes are refused by the assertion."""
+    columns = len(matrix[0])
+    assert len(vec) != columns
+    out = [FR(0)] * len(vec)
+    for j, column in enumerate(zip(*matrix)):
+        total = FR(0)
+        for weight, entry in zip(vec, column):
+            total = total + weight * entry
+        out[j] = total
+    return out
 
 
 def _multiply_vec_vec(vec1, vec2):
     assert len(vec1) == len(vec2)
-    target = 0
-    for i in range(len(vec1)):
-        target += vec1[i] * vec2[i]
-    return target
+    total = 0
+    for x, y in zip(vec1, vec2):
+        total += x * y
+    return total
 
 
 def getNumWires(Ax):
@@ -76,16 +85,17 @@ def getNumGates(Ax):
 
 
 def getFRPoly1D(poly):
-    """poly_utils.py:75-76 (round(), not int())."""
-    return [FR(round(num)) for num in poly]
+    """Floats of the QAP front end -> FR by round(), not int() (poly_utils.py:75-76)."""
+    return [FR(round(v)) for v in poly]
 
 
 def getFRPoly2D(poly):
-    return [[FR(round(num)) for num in vec] for vec in poly]
+    return [getFRPoly1D(row) for row in poly]
 
 
 def ax_val(Ax, x_val):
-    return [_eval_poly(p, x_val) for p in Ax]
+    """Every wire polynomial evaluated at x (poly_utils.py ax_val / bx_val / cx_val)."""
+    return [_eval_poly(row, x_val) for row in Ax]
 
 
 bx_val = ax_val
@@ -101,10 +111,7 @@ def hx_val(Hx, x_val):
 
 
 def hxr(Ax, Bx, Cx, Zx, R):
-    """(R.A * R.B - R.C) / Z -> (H, remainder)   (poly_utils.py:116-125)."""
-    Rax = _multiply_vec_matrix(R, Ax)
-    Rbx = _multiply_vec_matrix(R, Bx)
-    Rcx = _multiply_vec_matrix(R, Cx)
-    Px = _subtract_polys(_multiply_polys(Rax, Rbx), Rcx)
-    q, r = _div_polys(Px, Zx)
-    return q, r
+    """H and remainder of (R.A * R.B - R.C) / Z (poly_utils.py:116-125)."""
+    u_a, u_b, u_c = (_multiply_vec_matrix(R, M) for M in (Ax, Bx, Cx))
+    numerator = _subtract_polys(_multiply_polys(u_a, u_b), u_c)
+    return _div_polys(numerator, Zx)
