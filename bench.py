@@ -288,33 +288,71 @@ def main():
             agg = world * 2 * reps * m / span   # wall clock between barriers (includes launch latency), all ranks
             extra["ntt"]["all_gpus"] = {"mode": "one polynomial per GPU, no exchange", "elements_per_s": agg,
                                         "hbm_frac_per_gpu": 64.0 * agg / world / 1e9 / HBM_PEAK_GBS}
+        if rank == 0 and world == 1 and args.cpu_sample:
+            # CPU lines beside the NTT (row D4): the reference-shaped recursive fft (polynomial.py:292-341) in pure Python on the
+            # first 2^16 coefficients, and the C oracle's iterative NTT on the whole vector -- each compared with the GPU output
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import py_ref
+            import c_oracle
+            Ls = min(16, L)
+            ms_ = 1 << Ls
+            small = torch.from_numpy(coeffs[:ms_].copy().view(np.int64)).to(dev)
+            NttPlan(Ls).run(small.data_ptr(), False, None, stream)
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            py_out = py_ref.fft(_lib.limbs_to_ints(coeffs[:ms_]), py_ref.get_root_of_unity(ms_))
+            pdt = time.perf_counter() - p0
+            same_py = _lib.limbs_to_ints(small.cpu().numpy().view(np.uint64).reshape(-1, 4)) == [int(v) for v in py_out]
+            nplan.run(d.data_ptr(), False, None, stream)
+            torch.cuda.synchronize()
+            gpu_fwd = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
+            nplan.run(d.data_ptr(), True, None, stream)
+            c0_ = time.perf_counter()
+            c_out = c_oracle.ntt_arr(coeffs, py_ref.get_root_of_unity(m))
+            cdt_ = time.perf_counter() - c0_
+            extra["ntt"]["cpu_baseline"] = {
+                "value": ms_ / pdt, "unit": "elements/s", "cores": 1, "kind": "port",
+                "sample": "first 2^%d coefficients, oracle/py_ref.fft (recursive radix-2, as zkp/plonk/polynomial.py:292-341); %.2f s; "
+                          "equals the GPU transform of the same sample: %s" % (Ls, pdt, same_py),
+                "compiled_c": {"value": m / cdt_, "unit": "elements/s", "cores": 1, "kind": "port",
+                               "sample": "all 2^%d coefficients, oracle/bn254_oracle.c orc_ntt; %.2f s; bit-identical to the GPU forward transform: %s"
+                                         % (L, cdt_, bool(np.array_equal(gpu_fwd, c_out)))}}
         del d, ref
         # ONE transform of 2^24 points spread over the ranks (four-step, one all-to-all; zkhip.distributed.DistNtt)
         if dist_on and args.dist_ntt_log_n:
-          try:
-              from zkhip.distributed import DistNtt
-              dn = DistNtt(args.dist_ntt_log_n)
-              rows, cols = dn.local_shape_in()
-              x0 = torch.from_numpy(random_scalars(np.random.default_rng(0x5EEDB270 + rank), rows * cols).view(np.int64).reshape(rows, cols, 4)).to(dev)
-              x = x0.clone()
-              back = dn.inverse(dn.forward(x))
-              ok_rt = bool(torch.equal(back, x0))
-              x = x0.clone()
-              fence()
-              td0 = time.perf_counter()
-              dreps = 3
-              for _ in range(dreps):
-                  y = dn.forward(x)
-                  x = y if dn.l1 == dn.l2 else x0.clone()     # even log n: the output layout is the input layout again
-              fence()
-              dms = (time.perf_counter() - td0) / dreps * 1e3
-              tt = torch.tensor([dms, 0.0 if ok_rt else 1.0], dtype=torch.float64, device=dev)
-              dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-              extra["dist_ntt"] = {"log_n": args.dist_ntt_log_n, "ms_per_forward": round(float(tt[0].item()), 4),
-                                   "elements_per_s": (1 << args.dist_ntt_log_n) / (float(tt[0].item()) * 1e-3), "roundtrip_exact": float(tt[1].item()) == 0.0}
-              del x, x0, back, y
-          except Exception as exc:  # noqa: BLE001 -- a secondary measurement must not take the headline line down with it
-            extra["dist_ntt"] = {"error": repr(exc)}
+            # set-up may fail on one rank only (memory): agree first, so that no rank waits alone in the all-to-all
+            dn = x0 = None
+            try:
+                from zkhip.distributed import DistNtt
+                dn = DistNtt(args.dist_ntt_log_n)
+                rows, cols = dn.local_shape_in()
+                x0 = torch.from_numpy(random_scalars(np.random.default_rng(0x5EEDB270 + rank), rows * cols).view(np.int64).reshape(rows, cols, 4)).to(dev)
+            except Exception as exc:  # noqa: BLE001 -- a secondary measurement must not take the headline line down with it
+                dn = None
+                sys.stderr.write("dist_ntt set-up failed on rank %d: %r\n" % (rank, exc))
+            ready = torch.tensor([1.0 if dn is not None else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+            if float(ready.item()) == 1.0:
+                x = x0.clone()
+                back = dn.inverse(dn.forward(x))
+                ok_rt = bool(torch.equal(back, x0))
+                x = x0.clone()
+                fence()
+                td0 = time.perf_counter()
+                dreps = 3
+                for _ in range(dreps):
+                    y = dn.forward(x)
+                    x = y if dn.l1 == dn.l2 else x0.clone()     # even log n: the output layout is the input layout again
+                fence()
+                dms = (time.perf_counter() - td0) / dreps * 1e3
+                tt = torch.tensor([dms, 0.0 if ok_rt else 1.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                extra["dist_ntt"] = {"log_n": args.dist_ntt_log_n, "ms_per_forward": round(float(tt[0].item()), 4),
+                                     "elements_per_s": (1 << args.dist_ntt_log_n) / (float(tt[0].item()) * 1e-3), "roundtrip_exact": float(tt[1].item()) == 0.0}
+                del x, back, y
+            else:
+                extra["dist_ntt"] = {"error": "setup failed on some rank"}
+            del x0, dn
 
     # ---- secondary: "witness-like" scalars: half the scalars are 0 or 1, the rest uniform
     if rank == 0 and world == 1 and not args.no_witness_like:
