@@ -38,9 +38,17 @@ __global__ __launch_bounds__(64) void msm_fixed_table_kernel(const uint32_t *__r
 }
 
 // digits[w * n_pad + i] = signed 20-bit digit w of scalar i (int32); cell_total[g] += digits whose bucket lies in cell g.
+//
+// spread (G1 only): a canonical scalar has 254 bits, so the top row's digits (bits 240..253) would fall on the lowest 2^14
+// of the 2^19 buckets -- 64 extra entries on each, lists of ~90 where the mean is 26, and the threads that own them finish
+// long after the rest of the grid (accumulate 1.31 ms where 13 n additions need 1.02).  Every point of G1 has order r
+// (cofactor 1), so k P = (k + m r) P: scalar i is replaced by k + m_i r with m_i in [0, 40] taken from the index, which
+// makes the top digit uniform over [0, 0.96 * 2^19) like every other row's.  Scalars below 2^240 (their top digit is zero:
+// small / witness-like values keep their few non-zero digits) and non-canonical ones >= 2^254 are left alone.  Not for
+// G2: the twist has a cofactor, and an input outside the order-r subgroup must still give the reference's result.
 template <int DUMMY>
 __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32_t *__restrict__ scalars, int32_t *__restrict__ digits,
-                                                                   uint32_t *__restrict__ cell_total, uint32_t n, uint32_t n_pad) {
+                                                                   uint32_t *__restrict__ cell_total, uint32_t n, uint32_t n_pad, bool spread) {
     constexpr int C = FIX_C, W = FIX_W;
     __shared__ uint32_t hist[FIX_G];
     const uint32_t t = threadIdx.x;
@@ -54,17 +62,31 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32
             for (int w = 0; w < W; w++) digits[(size_t)w * n_pad + i] = 0;
             continue;
         }
-        uint32_t s[8];
+        uint32_t s[9];
         ld_words<8>(scalars + (size_t)i * 8, s);
+        s[8] = 0;
+        if (spread && (s[7] >> 16) != 0 && (s[7] >> 30) == 0) {
+            // r as 32-bit words, least significant first
+            constexpr uint32_t RW[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+            const uint32_t m = ((i * 0x9E3779B1u) >> 16) % 41u;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                acc += (uint64_t)m * RW[k] + s[k];
+                s[k] = (uint32_t)acc;
+                acc >>= 32;
+            }
+            s[8] = (uint32_t)acc;   // k + m r < 2^254 + 40 r < 2^259 - 2^240: the signed top digit stays below 2^19
+        }
         uint32_t carry = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) {
             constexpr uint32_t mask = (1u << C) - 1u;
             const int off = w * C, word = off >> 5, sh = off & 31;
             uint32_t raw = 0;
-            if (word < 8) {
+            if (word < 9) {
                 raw = s[word] >> sh;
-                if (sh + C > 32 && word + 1 < 8) raw |= s[word + 1] << (32 - sh);
+                if (sh + C > 32 && word + 1 < 9) raw |= s[word + 1] << (32 - sh);
             }
             raw &= mask;
             const uint32_t v = raw + carry;

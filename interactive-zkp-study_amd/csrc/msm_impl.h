@@ -941,7 +941,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         ZK_HIP(hipStreamWaitEvent(ls, L.ev_in, 0));
         mark(L, 0);
         hipLaunchKernelGGL((msm_fixed_prepare_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, ls, static_cast<const uint32_t *>(d_scalars),
-                           L.digits32.template as<int32_t>(), L.cells.template as<uint32_t>(), (uint32_t)n, n_pad);
+                           L.digits32.template as<int32_t>(), L.cells.template as<uint32_t>(), (uint32_t)n, n_pad, F::CANON_WORDS == 8);
         ZK_HIP(hipEventRecord(L.ev_consumed, ls));
         ZK_HIP(hipStreamWaitEvent(st, L.ev_consumed, 0));
         mark(L, 1);
