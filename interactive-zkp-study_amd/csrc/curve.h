@@ -85,8 +85,8 @@ template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) 
     F pp = fe_sqr(p);                        // 10*10 < 169
     F ppp = fe_mul(p, pp);
     F qq = fe_mul(acc.x, pp);                // 8*2
-    F x3 = fe_sub<6>(fe_sqr(r), fe_add(ppp, fe_dbl(qq)));           // < 8m
-    F y3 = fe_mulsub<4>(r, fe_sub<8>(qq, x3), acc.y, ppp);           // 6*10 + 4*2 < 169;  < 2m
+    F x3 = fe_sub2<6>(fe_sqr(r), ppp, qq);                           // r^2 - ppp - 2 qq;  < 8m
+    F y3 = fe_mulsub<4>(r, fe_sub_once<8>(qq, x3), acc.y, ppp);      // 6*11 + 5*2 < 169;  < 2m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(acc.zz, pp);
@@ -116,8 +116,8 @@ template <class F> ZK_HD void xyzz_add(Xyzz<F> &acc, const Xyzz<F> &q) {
     F pp = fe_sqr(p);
     F ppp = fe_mul(p, pp);
     F qq = fe_mul(u1, pp);
-    F x3 = fe_sub<6>(fe_sqr(r), fe_add(ppp, fe_dbl(qq)));           // < 8m
-    F y3 = fe_mulsub<2>(r, fe_sub<8>(qq, x3), s1, ppp);              // 4*10 + 2*2 < 169;  < 2m
+    F x3 = fe_sub2<6>(fe_sqr(r), ppp, qq);                           // < 8m
+    F y3 = fe_mulsub<2>(r, fe_sub_once<8>(qq, x3), s1, ppp);         // 4*11 + 3*2 < 169;  < 2m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);

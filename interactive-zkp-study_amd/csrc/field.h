@@ -80,6 +80,11 @@ template <class Tag> struct FieldConst;
             constexpr uint32_t m[17][NL] = PFX##_KP;                                      \
             return m[k][i];                                                               \
         }                                                                                 \
+        /* k * modulus again, with 2^29 lent to every limb below the top one (and taken back from the   */ \
+        /* limb above): kpl(k, i) - b.l[i] is non-negative for every normalised b <= (k-1) * modulus     */ \
+        static ZK_HD uint32_t kpl(int k, int i) {                                         \
+            return kp(k, i) + (i < NL - 1 ? (1u << LB) : 0u) - (i > 0 ? 1u : 0u);         \
+        }                                                                                 \
         static constexpr uint32_t inv = PFX##_INV29;                                      \
     };
 ZK_DEFINE_FIELD_CONST(FpTag, ZK_FP)
@@ -171,15 +176,12 @@ template <class Tag> ZK_HD Fe<Tag> fe_reduce_full(Fe<Tag> a) {
 }
 
 template <class Tag> ZK_HD bool Fe<Tag>::is_zero() const {
-    // Quick reject: a multiple of m below 16m must match k*m in its lowest limb for some k.
+    // Quick reject in three instructions: a value k*m with k < 16 has k*m_0 in its low 29 bits, so
+    // l_0 * m_0^-1 mod 2^29 must come out below 16 (C::inv is -m_0^-1).  The low 29 bits of l[0] are those
+    // of the value whether or not the limbs are normalised.
     ZK_DBG_ASSERT(vb <= 16, "is_zero: value bound exceeds 16 m");
-    Fe t = *this;
-    fe_normalize(t);
-    bool maybe = false;
-#pragma unroll
-    for (int k = 0; k < 16; k++) maybe |= (t.l[0] == C::kp(k, 0));
-    if (!maybe) return false;
-    return fe_reduce_full(t).raw_is_zero();
+    if ((((0u - l[0]) * C::inv) & LMASK) >= 16u) return false;
+    return fe_reduce_full(*this).raw_is_zero();
 }
 template <class Tag> ZK_HD bool Fe<Tag>::equals(const Fe &b) const {
     const Fe x = fe_reduce_full(*this), y = fe_reduce_full(b);
@@ -228,6 +230,43 @@ template <int K, class Tag> ZK_HD Fe<Tag> fe_neg_k(const Fe<Tag> &a) {
     ZK_DBG_ASSERT(a.vb <= K && a.lmax <= 3, "fe_neg_k<K>: operand may exceed K*m");
     fe_normalize(r);
     ZK_DBG(r.vb = K;)
+    return r;
+}
+// Unnormalised forms for values that go straight into ONE multiplication (fe_mul / fe_dot / fe_mulsub take limbs
+// up to a few 2^29: 9 * la * lb + 10 < 64 per product column): no carry propagation at all.
+//   fe_sub_lazy<K>: a - b + (K+1)*m, needs b normalised and <= K*m; limbs < (la + 2) * 2^29.
+//   fe_neg_lazy<K>: (K+1)*m - a,     same conditions on a;           limbs < 2 * 2^29.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_sub_lazy(const Fe<Tag> &a, const Fe<Tag> &b) {
+    typedef FieldConst<Tag> C;
+    static_assert(K + 1 <= 16, "fe_sub_lazy: no constant for (K+1)*m");
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + C::kpl(K + 1, i) - b.l[i];
+    ZK_DBG_ASSERT(b.vb <= K && b.lmax <= 1, "fe_sub_lazy<K>: subtrahend must be normalised and <= K*m");
+    ZK_DBG_ASSERT(a.lmax <= 2, "fe_sub_lazy: limb overflow");
+    ZK_DBG(r.vb = a.vb + K + 1; r.lmax = a.lmax + 2;)
+    return r;
+}
+template <int K, class Tag> ZK_HD Fe<Tag> fe_neg_lazy(const Fe<Tag> &a) {
+    typedef FieldConst<Tag> C;
+    static_assert(K + 1 <= 16, "fe_neg_lazy: no constant for (K+1)*m");
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = C::kpl(K + 1, i) - a.l[i];
+    ZK_DBG_ASSERT(a.vb <= K && a.lmax <= 1, "fe_neg_lazy<K>: operand must be normalised and <= K*m");
+    ZK_DBG(r.vb = K + 1; r.lmax = 2;)
+    return r;
+}
+// a - b - 2c + K*m with one carry propagation (the X coordinate of every addition); needs b + 2c <= K*m.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_sub2(const Fe<Tag> &a, const Fe<Tag> &b, const Fe<Tag> &c) {
+    typedef FieldConst<Tag> C;
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + C::kp(K, i) - b.l[i] - 2u * c.l[i];
+    ZK_DBG_ASSERT(b.vb + 2 * c.vb <= K, "fe_sub2<K>: b + 2c may exceed K*m");
+    ZK_DBG_ASSERT(a.lmax <= 2 && b.lmax <= 1 && c.lmax <= 1, "fe_sub2: limb overflow");
+    fe_normalize(r);
+    ZK_DBG(r.vb = a.vb + K;)
     return r;
 }
 template <class Tag> ZK_HD Fe<Tag> fe_dbl(const Fe<Tag> &a) {
@@ -282,8 +321,8 @@ template <class Tag> ZK_HD Fe<Tag> fe_mul(const Fe<Tag> &a, const Fe<Tag> &b) {
 }
 
 // sum_t a[t] * b[t] with ONE Montgomery reduction: the N products are accumulated column-wise before the
-// reduction runs, saving (N-1) * (81 + 9) multiply-adds over N separate fe_mul.  Operands must be normalised
-// (limbs < 2^29: N * 9 + 10 columns-units < 64) and sum_t va[t] * vb[t] < 169;  result < 2m.
+// reduction runs, saving (N-1) * (81 + 9) multiply-adds over N separate fe_mul.  Operands: limbs < la, lb times 2^29
+// with sum_t 9 la[t] lb[t] + 10 < 64 (normalised operands: N * 9 + 10), values sum_t va[t] * vb[t] < 169;  result < 2m.
 template <int N, class Tag> ZK_HD Fe<Tag> fe_dot(const Fe<Tag> *const (&a)[N], const Fe<Tag> *const (&b)[N]) {
     typedef FieldConst<Tag> C;
     static_assert(N * 9 + 10 < 64, "fe_dot: column accumulator would overflow");
@@ -315,20 +354,22 @@ template <int N, class Tag> ZK_HD Fe<Tag> fe_dot(const Fe<Tag> *const (&a)[N], c
     }
     r.l[NL - 1] = (uint32_t)acc;
 #ifdef ZK_FIELD_DEBUG
-    double vsum = 0;
+    double vsum = 0, lsum = 0;
     for (int t = 0; t < N; t++) {
         vsum += a[t]->vb * b[t]->vb;
-        ZK_DBG_ASSERT(a[t]->lmax <= 1 && b[t]->lmax <= 1, "fe_dot: operands must be normalised");
+        lsum += 9.0 * a[t]->lmax * b[t]->lmax;
     }
+    ZK_DBG_ASSERT(lsum + 9.0 + 1.0 < 64.0, "fe_dot: column accumulator may overflow");
     ZK_DBG_ASSERT(vsum < 169.0, "fe_dot: sum of value bounds >= 169");
     r.vb = vsum / 169.0 + 1.0;
     r.lmax = 1;
 #endif
     return r;
 }
-// a*b - c*d (c <= K*m), one reduction;  result < 2m.
+// a*b - c*d (c normalised, <= K*m), one reduction;  result < 2m.  a or b may be a lazy difference (fe_sub_lazy);
+// values: va*vb + (K+1)*vd < 169.
 template <int K, class Tag> ZK_HD Fe<Tag> fe_mulsub(const Fe<Tag> &a, const Fe<Tag> &b, const Fe<Tag> &c, const Fe<Tag> &d) {
-    const Fe<Tag> nc = fe_neg_k<K>(c);
+    const Fe<Tag> nc = fe_neg_lazy<K>(c);
     const Fe<Tag> *const x[2] = {&a, &nc};
     const Fe<Tag> *const y[2] = {&b, &d};
     return fe_dot<2>(x, y);
@@ -443,6 +484,8 @@ typedef Fe<FrTag> Fr;
 // mul outputs are < 2m, which is what the K arguments in curve.h are derived from.
 template <int K, class Tag> ZK_HD Fe<Tag> fe_sub(const Fe<Tag> &a, const Fe<Tag> &b) { return fe_sub_k<K>(a, b); }
 template <int K, class Tag> ZK_HD Fe<Tag> fe_neg(const Fe<Tag> &a) { return fe_neg_k<K>(a); }
+// fe_sub_once<K>(a, b): a - b for a result that is used as ONE multiplication operand and nothing else.
+template <int K, class Tag> ZK_HD Fe<Tag> fe_sub_once(const Fe<Tag> &a, const Fe<Tag> &b) { return fe_sub_lazy<K>(a, b); }
 
 // ---------------------------------------------------------------------------------------
 // F_p^2 = F_p[i]/(i^2+1); element c0 + c1*i  (py_ecc FQ2, coeffs [c0, c1]).
@@ -470,10 +513,17 @@ template <int K> ZK_HD Fp2 fe_sub(const Fp2 &a, const Fp2 &b) {  // inputs < 2p 
     return r;
 }
 template <int K> ZK_HD Fp2 fe_neg(const Fp2 &a) { return Fp2{fe_neg_k<2>(a.c0), fe_neg_k<2>(a.c1)}; }
+template <int K> ZK_HD Fp2 fe_sub_once(const Fp2 &a, const Fp2 &b) { return fe_sub<K>(a, b); }  // F_p^2 keeps components < 2p
 ZK_HD Fp2 fe_dbl(const Fp2 &a) {
     Fp2 r{fe_dbl(a.c0), fe_dbl(a.c1)};
     fe_wreduce<4>(r.c0);
     fe_wreduce<4>(r.c1);
+    return r;
+}
+template <int K> ZK_HD Fp2 fe_sub2(const Fp2 &a, const Fp2 &b, const Fp2 &c) {  // a - b - 2c; inputs < 2p per component
+    Fp2 r{fe_sub2<6>(a.c0, b.c0, c.c0), fe_sub2<6>(a.c1, b.c1, c.c1)};             // < 8p
+    fe_wreduce<8>(r.c0);
+    fe_wreduce<8>(r.c1);
     return r;
 }
 ZK_HD Fp2 fe_triple(const Fp2 &a) {

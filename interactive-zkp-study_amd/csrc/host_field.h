@@ -116,6 +116,8 @@ template <class Tag> inline HFe<Tag> fe_triple(const HFe<Tag> &a) { return fe_ad
 // curve.h passes value-bound hints K for the lazy device representation; host elements are always canonical.
 template <int K, class Tag> inline HFe<Tag> fe_sub(const HFe<Tag> &a, const HFe<Tag> &b) { return fe_sub(a, b); }
 template <int K, class Tag> inline HFe<Tag> fe_neg(const HFe<Tag> &a) { return fe_neg(a); }
+template <int K, class Tag> inline HFe<Tag> fe_sub_once(const HFe<Tag> &a, const HFe<Tag> &b) { return fe_sub(a, b); }
+template <int K, class Tag> inline HFe<Tag> fe_sub2(const HFe<Tag> &a, const HFe<Tag> &b, const HFe<Tag> &c) { return fe_sub(fe_sub(a, b), fe_dbl(c)); }
 template <class Tag> inline HFe<Tag> fe_mul(const HFe<Tag> &a, const HFe<Tag> &b) {
     static const HFe<Tag> m = HFe<Tag>::modulus();
     static const uint64_t inv = HFe<Tag>::inv64();
@@ -187,6 +189,8 @@ inline HFp2 fe_dbl(const HFp2 &a) { return HFp2{fe_dbl(a.c0), fe_dbl(a.c1)}; }
 inline HFp2 fe_triple(const HFp2 &a) { return HFp2{fe_triple(a.c0), fe_triple(a.c1)}; }
 template <int K> inline HFp2 fe_sub(const HFp2 &a, const HFp2 &b) { return fe_sub(a, b); }
 template <int K> inline HFp2 fe_neg(const HFp2 &a) { return fe_neg(a); }
+template <int K> inline HFp2 fe_sub_once(const HFp2 &a, const HFp2 &b) { return fe_sub(a, b); }
+template <int K> inline HFp2 fe_sub2(const HFp2 &a, const HFp2 &b, const HFp2 &c) { return fe_sub(fe_sub(a, b), fe_dbl(c)); }
 inline HFp2 fe_mul(const HFp2 &a, const HFp2 &b) {
     HFp v0 = fe_mul(a.c0, b.c0), v1 = fe_mul(a.c1, b.c1);
     HFp s = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
