@@ -536,7 +536,7 @@ ZK_HD Fp2 fe_triple(const Fp2 &a) {
 // Montgomery reductions (fe_dot<2>), cheaper here than Karatsuba's three full multiplications plus its
 // additions.  Components < 2p in, < 2p out (sum of value bounds 8 < 169).
 ZK_HD Fp2 fe_mul(const Fp2 &a, const Fp2 &b) {
-    const Fp nb1 = fe_neg_k<2>(b.c1);
+    const Fp nb1 = fe_neg_lazy<2>(b.c1);   // 3p - b1, limbs < 2 * 2^29: column bound 9 + 18 + 10 < 64
     const Fp *const x[2] = {&a.c0, &a.c1};
     const Fp *const y0[2] = {&b.c0, &nb1};
     const Fp *const y1[2] = {&b.c1, &b.c0};
@@ -544,7 +544,8 @@ ZK_HD Fp2 fe_mul(const Fp2 &a, const Fp2 &b) {
 }
 // a*b - c*d in F_p^2 with two reductions (fe_dot<4> per component).  K is ignored: components are < 2p.
 template <int K> ZK_HD Fp2 fe_mulsub(const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
-    const Fp nb1 = fe_neg_k<2>(b.c1), nc0 = fe_neg_k<2>(c.c0), nc1 = fe_neg_k<2>(c.c1);
+    // nc0 enters both components next to another lazy operand, so it stays normalised: 9 + 18 + 9 + 9 + 10 < 64
+    const Fp nb1 = fe_neg_lazy<2>(b.c1), nc0 = fe_neg_k<2>(c.c0), nc1 = fe_neg_lazy<2>(c.c1);
     const Fp *const x0[4] = {&a.c0, &a.c1, &nc0, &c.c1};
     const Fp *const y0[4] = {&b.c0, &nb1, &d.c0, &d.c1};
     const Fp *const x1[4] = {&a.c0, &a.c1, &nc0, &nc1};

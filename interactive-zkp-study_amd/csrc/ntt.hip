@@ -50,9 +50,12 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
 
 // R butterfly stages (s_hi .. s_hi-R+1) on 2^R elements held in registers: LDS is read and written
 // once per element per round instead of once per stage, and a stage's twiddle is fetched once per
-// 2^(R-1-b) butterflies.  Values stay < 2r (see the pass kernel).
+// 2^(R-1-b) butterflies.  Values stay < 2r (see the pass kernel).  A difference that goes into its twiddle
+// multiplication and nowhere else is formed without carry propagation (fe_sub_lazy: a - b + 3r, limbs < 3 * 2^29).
 // LAST: the round that ends at stage 0 (s_lo == 0): there `low` is 0, so every q == 0 twiddle is w^0 = 1
 // and those butterflies skip the multiplication (all of stage 0, half of stage 1, a quarter of stage 2).
+// (Leaving the sums unreduced until the end of a round -- 7 conditional subtractions per 8 elements instead of 12 --
+// was tried: it needs 288 registers, and at one wavefront per SIMD the pass is 30 % slower; capped at 256 it spills.)
 template <int R, bool LAST>
 __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, uint32_t tile, uint32_t ntw, uint32_t lp, uint32_t g,
                                           int s_hi) {
@@ -78,11 +81,13 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
                     const int k0 = (hi << (b + 1)) | q, k1 = k0 | (1 << b);
                     Fr sum = fe_add(x[k0], x[k1]);  // < 4r
                     fe_wreduce<4>(sum);             // < 2r
-                    Fr dif = fe_sub_k<2>(x[k0], x[k1]);  // (a - b + 2r) < 4r
-                    if (unit)
-                        fe_wreduce<4>(dif);         // < 2r
-                    else
-                        dif = fe_mul(dif, w);       // w < r  ->  < 2r
+                    Fr dif;
+                    if (unit) {
+                        dif = fe_sub_k<2>(x[k0], x[k1]);  // (a - b + 2r) < 4r
+                        fe_wreduce<4>(dif);               // < 2r
+                    } else {
+                        dif = fe_mul(fe_sub_lazy<2>(x[k0], x[k1]), w);  // (a - b + 3r) < 5r, w < r  ->  < 2r
+                    }
                     x[k1] = dif;
                     x[k0] = sum;
                 }
