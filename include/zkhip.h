@@ -97,7 +97,7 @@ int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_p
  * point; the plan must have been created for more than 2^17 points, and 13 n < 2^31).  Afterwards every MSM call of the plan
  * that passes d_points == NULL uses the first n bound bases: one window of 2^19 buckets over the 13 n table entries the
  * signed 20-bit digits select -- 13 n bucket additions instead of 16 n and a single window to reduce.  n == 0 unbinds.
- * Results are identical to the unbound calls.  (G1: a canonical scalar k >= 2^240 is run as k + m r with a small m taken
+ * Results are identical to the unbound calls.  (G1, here and in the unbound calls: a canonical scalar k >= 2^240 is run as k + m r with a small m taken
  * from its index, which evens out the top row's bucket load; every point of the curve y^2 = x^3 + 3 has order r, so the sum
  * is the same -- for bases that are not on the curve the two modes may differ, and neither matches anything.) */
 int zk_msm_plan_bind_points(zk_msm_plan *plan, const void *d_points, size_t n, void *stream);
