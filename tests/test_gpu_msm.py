@@ -434,3 +434,35 @@ def test_bound_bases_mode_equals_unbound(group, monkeypatch):
     with pytest.raises(_lib.ZkhipError):
         plan.run_limbs(dS.data_ptr(), None, n, st)
     plan.close()
+
+
+def test_g1_top_window_spreading_edges():
+    """Above 2^17 points (16-bit windows) and in bound-bases mode a G1 scalar k >= 2^240 is run as k + m*r (the top window /
+    table row would otherwise use a fraction of its buckets).  The values around the 2^240 threshold and just below r sit
+    at odd and even positions here; both modes must give the closed form (sum s_i k_i) * G1."""
+    import torch
+    from bench import random_scalars
+    from helpers import arithmetic_dot, arithmetic_g1_points
+    n = (1 << 17) + 4097
+    k0, d = 0x0123456789ABCDE, 0x9E3779B1
+    rng = np.random.default_rng(240)
+    S = random_scalars(rng, n)
+    edge = [(1 << 240) - 1, 1 << 240, (1 << 240) + 1, o.R - 1, o.R - 2, 1 << 253, (1 << 253) + (1 << 240), o.R - (1 << 240),
+            (1 << 241) - 1, 0, 1, o.R - (1 << 239)]
+    for j, v in enumerate(edge):
+        S[1000 + 2 * j] = limb_row(v)          # even positions
+        S[2001 + 2 * j] = limb_row(v)          # odd positions: the ones the 16-window path shifts by r
+        S[n - 1 - j] = limb_row(v)
+    Pts = arithmetic_g1_points(_lib.load(), n, k0, d)
+    want = co.g1_mul(o.G1, arithmetic_dot(S, k0, d))
+    dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ints = lambda pt: tuple(int(c) for c in pt)
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    assert ints(plan.run(dS.data_ptr(), dP.data_ptr(), n, st)) == ints(want)
+    plan.bind(dP.data_ptr(), n, st)
+    assert ints(plan.run(dS.data_ptr(), None, n, st)) == ints(want)
+    # the same scalars on a short prefix go through the 15-bit-window path, which leaves them alone
+    m = 3000
+    assert ints(plan.run(dS.data_ptr(), dP.data_ptr(), m, st)) == ints(co.g1_mul(o.G1, arithmetic_dot(S[:m], k0, d)))
+    plan.close()
