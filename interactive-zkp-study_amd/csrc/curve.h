@@ -32,17 +32,17 @@ template <class F> struct Xyzz {
 template <class F> ZK_HD Affine<F> affine_neg(const Affine<F> &p) { return Affine<F>{p.x, fe_neg<2>(p.y)}; }
 template <class F> ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F> &p) { return Xyzz<F>{p.x, fe_neg<4>(p.y), p.zz, p.zzz}; }
 
-// 2*P for affine P (mdbl-2008-s-1).
+// 2*P for affine P (mdbl-2008-s-1); y may be up to 3m (a negated table entry).
 template <class F> ZK_HD Xyzz<F> xyzz_dbl_affine(const Affine<F> &p) {
     if (p.is_inf() || p.y.is_zero()) return Xyzz<F>::inf();
-    F u = fe_dbl(p.y);                       // < 4m
+    F u = fe_dbl(p.y);                       // < 6m
     F v = fe_sqr(u);
     F w = fe_mul(u, v);
     F s = fe_mul(p.x, v);
     F m = fe_triple(fe_sqr(p.x));            // < 6m
     Xyzz<F> r;
     r.x = fe_sub<4>(fe_sqr(m), fe_dbl(s));   // < 6m
-    r.y = fe_mulsub<2>(m, fe_sub<6>(s, r.x), p.y, w);  // 6*8 + 2*2 < 169;  < 2m
+    r.y = fe_mulsub<3>(m, fe_sub<6>(s, r.x), p.y, w);  // 6*8 + 4*2 < 169;  < 2m
     r.zz = v;
     r.zzz = w;
     return r;
@@ -64,29 +64,28 @@ template <class F> ZK_HD Xyzz<F> xyzz_dbl(const Xyzz<F> &p) {
     return r;
 }
 
-// acc += q, q affine (madd-2008-s), all exceptional cases handled.
+// acc += q, q affine (madd-2008-s), all exceptional cases handled.  q.y may be a single-use negation (fe_neg_once<2>:
+// value <= 3m, limbs not normalised): it only enters one product here; the two rare paths that keep it tidy it first.
 template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) {
     if (q.is_inf()) return;
     if (acc.is_inf()) {
-        acc = Xyzz<F>{q.x, q.y, F::one(), F::one()};
+        acc = Xyzz<F>{q.x, fe_tidy(q.y), F::one(), F::one()};   // Y <= 3m < 4m
         return;
     }
-    F u2 = fe_mul(q.x, acc.zz);
-    F s2 = fe_mul(q.y, acc.zzz);
-    F p = fe_sub<8>(u2, acc.x);              // < 10m
-    F r = fe_sub<4>(s2, acc.y);              // < 6m
+    F p = fe_mul_minus<8>(q.x, acc.zz, acc.x);   // U2 - X1;  < 10.1m
+    F r = fe_mul_minus<4>(q.y, acc.zzz, acc.y);  // S2 - Y1;  < 6.1m
     if (p.is_zero()) {
         if (r.is_zero())
-            acc = xyzz_dbl_affine(q);
+            acc = xyzz_dbl_affine(Affine<F>{q.x, fe_tidy(q.y)});
         else
             acc = Xyzz<F>::inf();
         return;
     }
-    F pp = fe_sqr(p);                        // 10*10 < 169
+    F pp = fe_sqr(p);                        // 10.1^2 < 169
     F ppp = fe_mul(p, pp);
     F qq = fe_mul(acc.x, pp);                // 8*2
     F x3 = fe_sub2<6>(fe_sqr(r), ppp, qq);                           // r^2 - ppp - 2 qq;  < 8m
-    F y3 = fe_mulsub<4>(r, fe_sub_once<8>(qq, x3), acc.y, ppp);      // 6*11 + 5*2 < 169;  < 2m
+    F y3 = fe_mulsub<4>(r, fe_sub_once<8>(qq, x3), acc.y, ppp);      // 6.1*11 + 5*2 < 169;  < 2m
     acc.x = x3;
     acc.y = y3;
     acc.zz = fe_mul(acc.zz, pp);

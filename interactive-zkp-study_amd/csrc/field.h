@@ -320,6 +320,43 @@ template <class Tag> ZK_HD Fe<Tag> fe_mul(const Fe<Tag> &a, const Fe<Tag> &b) {
     return r;
 }
 
+// a*b - c in the Montgomery domain (c normalised, <= K*m) with no separate subtraction: (K+1)*m - c is added to the
+// UPPER half of the double-width product (limb j lands in column NL + j, i.e. times R), so the one reduction delivers
+// (a*b + ((K+1)*m - c)*R) / R = a*b/R + (K+1)*m - c.  Nine column additions instead of a subtraction pass plus a carry
+// propagation; result normalised, value < va*vb/169 + K + 2 (in units of m).
+template <int K, class Tag> ZK_HD Fe<Tag> fe_mul_minus(const Fe<Tag> &a, const Fe<Tag> &b, const Fe<Tag> &c) {
+    typedef FieldConst<Tag> C;
+    const Fe<Tag> nc = fe_neg_lazy<K>(c);   // limbs < 2^30
+    uint32_t q[NL];
+    Fe<Tag> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        q[k] = ((uint32_t)acc * C::inv) & LMASK;
+        acc += (uint64_t)q[k] * C::mod(0);
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        acc += nc.l[k - NL];
+        r.l[k - NL] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    r.l[NL - 1] = (uint32_t)acc + nc.l[NL - 1];
+    ZK_DBG_ASSERT(a.vb * b.vb < 169.0, "fe_mul_minus: value bounds va*vb >= 169");
+    ZK_DBG_ASSERT(9.0 * a.lmax * b.lmax + 9.0 + 1.0 + 1.0 < 64.0, "fe_mul_minus: column accumulator may overflow");
+    ZK_DBG(r.vb = a.vb * b.vb / 169.0 + 1.0 + K + 1; r.lmax = 1;)
+    return r;
+}
+
 // sum_t a[t] * b[t] with ONE Montgomery reduction: the N products are accumulated column-wise before the
 // reduction runs, saving (N-1) * (81 + 9) multiply-adds over N separate fe_mul.  Operands: limbs < la, lb times 2^29
 // with sum_t 9 la[t] lb[t] + 10 < 64 (normalised operands: N * 9 + 10), values sum_t va[t] * vb[t] < 169;  result < 2m.
@@ -486,6 +523,13 @@ template <int K, class Tag> ZK_HD Fe<Tag> fe_sub(const Fe<Tag> &a, const Fe<Tag>
 template <int K, class Tag> ZK_HD Fe<Tag> fe_neg(const Fe<Tag> &a) { return fe_neg_k<K>(a); }
 // fe_sub_once<K>(a, b): a - b for a result that is used as ONE multiplication operand and nothing else.
 template <int K, class Tag> ZK_HD Fe<Tag> fe_sub_once(const Fe<Tag> &a, const Fe<Tag> &b) { return fe_sub_lazy<K>(a, b); }
+// fe_neg_once<K>(a): -a, again only as one multiplication operand (value <= (K+1)*m, limbs < 2^30); fe_tidy makes such a
+// value an ordinary normalised element again (same value).
+template <int K, class Tag> ZK_HD Fe<Tag> fe_neg_once(const Fe<Tag> &a) { return fe_neg_lazy<K>(a); }
+template <class Tag> ZK_HD Fe<Tag> fe_tidy(Fe<Tag> a) {
+    fe_normalize(a);
+    return a;
+}
 
 // ---------------------------------------------------------------------------------------
 // F_p^2 = F_p[i]/(i^2+1); element c0 + c1*i  (py_ecc FQ2, coeffs [c0, c1]).
@@ -514,6 +558,8 @@ template <int K> ZK_HD Fp2 fe_sub(const Fp2 &a, const Fp2 &b) {  // inputs < 2p 
 }
 template <int K> ZK_HD Fp2 fe_neg(const Fp2 &a) { return Fp2{fe_neg_k<2>(a.c0), fe_neg_k<2>(a.c1)}; }
 template <int K> ZK_HD Fp2 fe_sub_once(const Fp2 &a, const Fp2 &b) { return fe_sub<K>(a, b); }  // F_p^2 keeps components < 2p
+template <int K> ZK_HD Fp2 fe_neg_once(const Fp2 &a) { return fe_neg<K>(a); }
+ZK_HD Fp2 fe_tidy(const Fp2 &a) { return a; }
 ZK_HD Fp2 fe_dbl(const Fp2 &a) {
     Fp2 r{fe_dbl(a.c0), fe_dbl(a.c1)};
     fe_wreduce<4>(r.c0);
@@ -542,6 +588,7 @@ ZK_HD Fp2 fe_mul(const Fp2 &a, const Fp2 &b) {
     const Fp *const y1[2] = {&b.c1, &b.c0};
     return Fp2{fe_dot<2>(x, y0), fe_dot<2>(x, y1)};
 }
+template <int K> ZK_HD Fp2 fe_mul_minus(const Fp2 &a, const Fp2 &b, const Fp2 &c) { return fe_sub<K>(fe_mul(a, b), c); }
 // a*b - c*d in F_p^2 with two reductions (fe_dot<4> per component).  K is ignored: components are < 2p.
 template <int K> ZK_HD Fp2 fe_mulsub(const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
     // nc0 enters both components next to another lazy operand, so it stays normalised: 9 + 18 + 9 + 9 + 10 < 64

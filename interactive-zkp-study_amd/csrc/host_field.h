@@ -117,6 +117,9 @@ template <class Tag> inline HFe<Tag> fe_triple(const HFe<Tag> &a) { return fe_ad
 template <int K, class Tag> inline HFe<Tag> fe_sub(const HFe<Tag> &a, const HFe<Tag> &b) { return fe_sub(a, b); }
 template <int K, class Tag> inline HFe<Tag> fe_neg(const HFe<Tag> &a) { return fe_neg(a); }
 template <int K, class Tag> inline HFe<Tag> fe_sub_once(const HFe<Tag> &a, const HFe<Tag> &b) { return fe_sub(a, b); }
+template <int K, class Tag> inline HFe<Tag> fe_neg_once(const HFe<Tag> &a) { return fe_neg(a); }
+template <class Tag> inline HFe<Tag> fe_tidy(const HFe<Tag> &a) { return a; }
+template <int K, class Tag> inline HFe<Tag> fe_mul_minus(const HFe<Tag> &a, const HFe<Tag> &b, const HFe<Tag> &c) { return fe_sub(fe_mul(a, b), c); }
 template <int K, class Tag> inline HFe<Tag> fe_sub2(const HFe<Tag> &a, const HFe<Tag> &b, const HFe<Tag> &c) { return fe_sub(fe_sub(a, b), fe_dbl(c)); }
 template <class Tag> inline HFe<Tag> fe_mul(const HFe<Tag> &a, const HFe<Tag> &b) {
     static const HFe<Tag> m = HFe<Tag>::modulus();
@@ -190,6 +193,8 @@ inline HFp2 fe_triple(const HFp2 &a) { return HFp2{fe_triple(a.c0), fe_triple(a.
 template <int K> inline HFp2 fe_sub(const HFp2 &a, const HFp2 &b) { return fe_sub(a, b); }
 template <int K> inline HFp2 fe_neg(const HFp2 &a) { return fe_neg(a); }
 template <int K> inline HFp2 fe_sub_once(const HFp2 &a, const HFp2 &b) { return fe_sub(a, b); }
+template <int K> inline HFp2 fe_neg_once(const HFp2 &a) { return fe_neg(a); }
+inline HFp2 fe_tidy(const HFp2 &a) { return a; }
 template <int K> inline HFp2 fe_sub2(const HFp2 &a, const HFp2 &b, const HFp2 &c) { return fe_sub(fe_sub(a, b), fe_dbl(c)); }
 inline HFp2 fe_mul(const HFp2 &a, const HFp2 &b) {
     HFp v0 = fe_mul(a.c0, b.c0), v1 = fe_mul(a.c1, b.c1);

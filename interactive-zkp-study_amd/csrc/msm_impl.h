@@ -496,7 +496,7 @@ __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ 
     for (uint32_t k = 0; k < len; k++) {
         const uint32_t e = lst[k];
         Affine<F> p = unpack_affine(pts[e & 0x7fffffffu]);
-        if (e >> 31) p.y = fe_neg<2>(p.y);
+        if (e >> 31) p.y = fe_neg_once<2>(p.y);   // enters one product (or is tidied on the rare paths)
         xyzz_add_affine(acc, p);
     }
     return acc;

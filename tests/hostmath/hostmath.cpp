@@ -121,7 +121,7 @@ void hm_g1_accumulate(const uint64_t *pts, uint32_t n, const uint8_t *negate, ui
     G1Xyzz acc = G1Xyzz::inf();
     for (uint32_t i = 0; i < n; i++) {
         G1Affine q = g1_load(pts + 8 * i);
-        if (negate && negate[i]) q = affine_neg(q);
+        if (negate && negate[i]) q.y = fe_neg_once<2>(q.y);   // as the accumulate kernel negates: a single-use, unnormalised value
         xyzz_add_affine(acc, q);
     }
     Xyzz<HFp> h{HFp::from_dev(acc.x), HFp::from_dev(acc.y), HFp::from_dev(acc.zz), HFp::from_dev(acc.zzz)};

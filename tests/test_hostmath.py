@@ -146,3 +146,7 @@ def test_long_accumulation_chain_keeps_bounds(hm):
     neg2 = np.array([0, 1, 1, 0], dtype=np.uint8)
     hm.hm_g1_accumulate(P(co.g1_to_arr(pts2)), ctypes.c_uint32(4), P(neg2), P(O))
     assert not O.any()
+    # negated entries on the two rare paths that keep q.y: first addition into an empty accumulator, doubling
+    for sel, negs, k in (([0], [1], -ks[0]), ([0, 0], [1, 1], -2 * ks[0]), ([1, 0, 0], [0, 1, 1], ks[1] - 2 * ks[0])):
+        hm.hm_g1_accumulate(P(co.g1_to_arr([pts[i] for i in sel])), ctypes.c_uint32(len(sel)), P(np.array(negs, dtype=np.uint8)), P(O))
+        assert co.g1_from_arr(O)[0] == co.g1_mul(o.G1, k % o.R)
