@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised stress of the MSM pipeline on one GPU: random sizes (including chunked ones through the test knob),
-scalar patterns and in-flight depths, every result checked against the closed form (sum s_i k_i) * G.
+scalar patterns, in-flight depths and the bound-bases mode, every result checked against the closed form (sum s_i k_i) * G.
     python tools/stress_msm.py --iters 60 [--seed 1]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +34,7 @@ def main():
     bad = 0
     for it in range(a.iters):
         g2 = rng.random() < 0.25
-        chunk = int(rng.choice([0, 12, 14]))
+        chunk = int(rng.choice([0, 12, 14, 18]))
         if chunk:
             os.environ["ZK_MSM_CHUNK_LOG"] = str(chunk)
         else:
@@ -42,7 +42,12 @@ def main():
         limit = 1 << (chunk or 22)
         cap = n2max if g2 else nmax
         n = int(min(cap, max(1, int(2 ** rng.uniform(0, np.log2(cap))) + int(rng.integers(0, 3)))))
+        if not g2 and rng.random() < 0.3:
+            n = int(rng.integers((1 << 17) + 1, cap + 1))          # the 16-bit-window / bound-bases range more often
         plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, n)
+        bound = n > (1 << 17) and chunk in (0, 18) and rng.random() < 0.6
+        if bound:
+            plan.bind((dP2 if g2 else dP1).data_ptr(), n, st)
         depth = int(rng.integers(1, plan.max_in_flight() + 1))
         jobs = []
         for j in range(int(rng.integers(1, 5))):
@@ -61,11 +66,11 @@ def main():
             if m > limit:                       # a chunked MSM takes all lanes: drain first, run it alone
                 res += [plan.collect_limbs(t) for t in pend]
                 pend = []
-                res.append(plan.collect_limbs(plan.submit(dS.data_ptr(), (dP2 if g2 else dP1).data_ptr(), m, st)))
+                res.append(plan.collect_limbs(plan.submit(dS.data_ptr(), None if bound else (dP2 if g2 else dP1).data_ptr(), m, st)))
                 continue
             if len(pend) == depth:
                 res.append(plan.collect_limbs(pend.pop(0)))
-            pend.append(plan.submit(dS.data_ptr(), (dP2 if g2 else dP1).data_ptr(), m, st))
+            pend.append(plan.submit(dS.data_ptr(), None if (bound and rng.random() < 0.8) else (dP2 if g2 else dP1).data_ptr(), m, st))
         res += [plan.collect_limbs(t) for t in pend]
         for (m, S, _), (limbs, inf) in zip(jobs, res):
             dot = limbs_dot_mod_r(S, K[:m]) if m else 0
@@ -73,7 +78,7 @@ def main():
             got = None if inf else (limbs_to_g2(limbs) if g2 else limbs_to_g1(limbs))[0]
             if got != want:
                 bad += 1
-                print("MISMATCH", it, "g2" if g2 else "g1", "n", n, "m", m, "chunk", chunk, "depth", depth, flush=True)
+                print("MISMATCH", it, "g2" if g2 else "g1", "n", n, "m", m, "chunk", chunk, "depth", depth, "bound", bound, flush=True)
         plan.close()
         if it % 10 == 9:
             print("iter", it + 1, "ok so far" if not bad else "FAILURES %d" % bad, flush=True)
