@@ -601,7 +601,7 @@ __global__ __launch_bounds__(HEAVY_CT) void msm_heavy_combine_kernel(SortBufs B,
 //   thread per step, depth = number of levels.
 // Afterwards O_l = x[2^l] and T = x[0] (per block for the block kernel, per window at the end).
 template <class F>
-__global__ __launch_bounds__(256, (F::CANON_WORDS == 8 ? 4 : 1)) void msm_reduce_block_kernel(Xyzz<F> *x, uint32_t BL) {
+__global__ __launch_bounds__(256, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_reduce_block_kernel(Xyzz<F> *x, uint32_t BL) {
     Xyzz<F> *blk = x + ((size_t)blockIdx.x << BL);
     const uint32_t t = threadIdx.x;
     for (uint32_t s = 0; s < BL; s++) {
