@@ -61,6 +61,24 @@ __global__ __launch_bounds__(256) void fr_powers_kernel(uint32_t *__restrict__ x
     stc(x + i * 8, fe_mul(ldc(x + i * 8), w));
 }
 
+// The two-level table itself, built on the device: out[i] = g^i for i < na, out[na + j] = (g^na)^j for j < nb; every
+// thread raises its base to its own index by square-and-multiply (at most ~28 products), so a call needs no host table,
+// no upload and no synchronisation.  g, gh = g^na: Montgomery form.
+__global__ __launch_bounds__(256) void fr_power_table_kernel(Fr *__restrict__ out, Fr g, Fr gh, uint32_t na, uint32_t nb) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= na + nb) return;
+    const Fr base = t < na ? g : gh;
+    uint32_t e = t < na ? t : t - na;
+    Fr acc = Fr::one(), sq = base;
+#pragma unroll 1
+    while (e) {
+        if (e & 1u) acc = fe_mul(acc, sq);
+        sq = fe_sqr(sq);
+        e >>= 1;
+    }
+    out[t] = acc;
+}
+
 // ------------------------------------------------------------------------------ PLONK quotient, fused
 // t[i] = (gate + alpha * (num - den) + alpha^2 * (z - 1) * L1) / Z_H on the evaluation coset (zkp/plonk/prover/round3.py:114-147
 // builds the same numerator by polynomial products and divides by Z_H with poly_div):
@@ -272,23 +290,15 @@ void FrVecScratch::scale_powers(void *d_data, size_t n, const uint64_t base[4], 
     while (((size_t)1 << L) < n) L++;
     const unsigned lh = (L + 1) / 2;
     const size_t na = (size_t)1 << lh, nb = ((n - 1) >> lh) + 1;
-    std::vector<Fr> h(na + nb);
     const HFr g = fe_to_mont(host_fr(base));
-    HFr cur = HFr::one();
-    for (size_t i = 0; i < na; i++) {
-        h[i] = cur.to_dev();
-        cur = fe_mul(cur, g);
-    }
-    const HFr gh = cur;  // g^(2^lh)
-    cur = HFr::one();
-    for (size_t i = 0; i < nb; i++) {
-        h[na + i] = cur.to_dev();
-        cur = fe_mul(cur, gh);
-    }
-    // the table buffer may still be read by an earlier call on this stream: order the upload behind it
-    ZK_HIP(hipStreamSynchronize(st));
-    if (tables.bytes < h.size() * sizeof(Fr)) tables.alloc(h.size() * sizeof(Fr));
-    ZK_HIP(hipMemcpy(tables.p, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice));
+    HFr gh = g;
+    for (unsigned i = 0; i < lh; i++) gh = fe_sqr(gh);  // g^(2^lh)
+    // The table is built by a kernel on the caller's stream (stream order protects an earlier call's readers); it is
+    // sized once for the largest domain (2^28: 2 * 2^14 entries) so that no call allocates.
+    const size_t cap = (size_t)2 << 14;
+    if (tables.bytes < std::max(cap, na + nb) * sizeof(Fr)) tables.alloc(std::max(cap, na + nb) * sizeof(Fr));
+    hipLaunchKernelGGL(fr_power_table_kernel, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, st, tables.as<Fr>(), g.to_dev(), gh.to_dev(),
+                       (uint32_t)na, (uint32_t)nb);
     hipLaunchKernelGGL(fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_data), tables.as<Fr>(),
                        tables.as<Fr>() + na, lh, n);
     ZK_HIP(hipGetLastError());

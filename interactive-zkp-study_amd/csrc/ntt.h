@@ -45,10 +45,11 @@ class NttPlan {
     DevBuf tile_tw_[2], twA_[2], twB_[2], twB_scaled_inv_;
     DevBuf tw_direct_[2][3];  // ready-made inter-pass twiddles of the small pass boundaries
     Fr scale_inv_;  // n^-1 (Montgomery)
-    // coset power tables (two-level), cached for the last (k, direction)
-    DevBuf cosA_, cosB_;
-    uint64_t cos_k_[4] = {0, 0, 0, 0};
-    int cos_dir_ = -1;
+    // coset power tables (two-level) of the last shift k, one pair per direction ([0]: k^i, [1]: k^-i): a prover alternates
+    // coset NTT and inverse with one fixed shift, and rebuilding means host work plus a blocking upload
+    DevBuf cosA_[2], cosB_[2];
+    uint64_t cos_k_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    bool cos_valid_[2] = {false, false};
 };
 
 // y = M x for a CSR matrix over F_r (u32 row_ptr[rows+1], u32 col[nnz], canonical vals[nnz], x, y) on device buffers.

@@ -333,15 +333,17 @@ void NttPlan::build_tables() {
 }
 
 void NttPlan::coset_tables(const uint64_t k[4], bool inverse) {
-    if (cos_dir_ == (int)inverse && !memcmp(cos_k_, k, 32)) return;
+    const int d = inverse ? 1 : 0;
+    if (cos_valid_[d] && !memcmp(cos_k_[d], k, 32)) return;
     HFr kk;
     memcpy(kk.l, k, 32);
     kk = fe_to_mont(kk);
     if (inverse) kk = fe_inv(kk);
-    upload_powers(cosA_, kk, (size_t)1 << lh_);
-    upload_powers(cosB_, hfr_pow_u64(kk, (uint64_t)1 << lh_), (size_t)1 << (L_ - lh_));
-    memcpy(cos_k_, k, 32);
-    cos_dir_ = (int)inverse;
+    ZK_HIP(hipDeviceSynchronize());  // a transform still in flight may be reading the tables this replaces
+    upload_powers(cosA_[d], kk, (size_t)1 << lh_);
+    upload_powers(cosB_[d], hfr_pow_u64(kk, (uint64_t)1 << lh_), (size_t)1 << (L_ - lh_));
+    memcpy(cos_k_[d], k, 32);
+    cos_valid_[d] = true;
 }
 
 void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st, unsigned batch) {
@@ -359,7 +361,7 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
     const unsigned blocks_sc = (unsigned)((n + 255) / 256);
     if (coset_shift && !inverse) {
         coset_tables(coset_shift, false);
-        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_.as<Fr>(), cosB_.as<Fr>(), lh_, n);
+        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_[0].as<Fr>(), cosB_[0].as<Fr>(), lh_, n);
     }
     if (L_ > 0 || inverse) {
         uint32_t sp = L_;
@@ -407,7 +409,7 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
     }
     if (coset_shift && inverse) {
         coset_tables(coset_shift, true);
-        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_.as<Fr>(), cosB_.as<Fr>(), lh_, n);
+        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_[1].as<Fr>(), cosB_[1].as<Fr>(), lh_, n);
     }
     ZK_HIP(hipGetLastError());
 }

@@ -96,14 +96,22 @@ class DevicePlonk:
         zh_inv = [pow((pow(COSET_K * pow(w_big, i, R) % R, n, R) - 1) % R, -1, R) for i in range(self.step)]
         self.zh_inv = zh_inv                                     # 1 / Z_H: x^n has period `step` on the coset
         self.work = [self._zeros(self.size) for _ in range(6)]   # per-proof coset buffers: a, b, c, z, z(omega x), t
+        # per-proof coefficient / scratch vectors, allocated once: prove() itself allocates nothing on the device, so the
+        # caching allocator never has to find (or release and re-acquire) twenty 32 MB blocks in the middle of a proof
+        self.buf = {k: self._zeros(n + PAD) for k in ("w0", "w1", "w2", "z", "num", "den", "tmp", "z_ev", "t0", "t1", "t2", "pw", "etmp",
+                                                      "r_poly", "numer", "dtmp", "q0", "q1")}
+        self.small = self._zeros(16)
 
     # ---- helpers -------------------------------------------------------------------------------------------
     def _zeros(self, rows):
         return _torch().zeros((rows, 4), dtype=_torch().int64, device="cuda")
 
-    def _interpolate(self, evals):
-        """(n, 4) evaluations on the domain -> zero-padded coefficient buffer (n + PAD, 4)."""
-        out = self._zeros(self.n + PAD)
+    def _interpolate(self, evals, out=None):
+        """(n, 4) evaluations on the domain -> zero-padded coefficient buffer (n + PAD, 4) (`out` when given)."""
+        if out is None:
+            out = self._zeros(self.n + PAD)
+        else:
+            out[self.n:].zero_()
         out[:self.n] = evals
         self.ntt_n.run(out.data_ptr(), True, None, self.st)
         return out
@@ -150,23 +158,23 @@ class DevicePlonk:
         """[(coef, count)] -> [p(point)]: the powers of the point are built once, every evaluation is an element-wise
         product and a running sum, and all values come back in one copy."""
         cmax = max(c for _, c in items)
-        pw = self.ones[:cmax].clone()
+        pw, tmp, res = self.buf["pw"], self.buf["etmp"], self.small[:len(items)]
+        pw[:cmax] = self.ones[:cmax]
         self.fv.scale_powers(pw.data_ptr(), cmax, int(point), self.st)
-        res = self._zeros(len(items))
-        tmp = self._zeros(cmax)
         for k, (coef, count) in enumerate(items):
             self._mul(tmp, coef, pw, count)
             self.fv.scan(tmp.data_ptr(), count, False, False, self.st)
             res[k:k + 1] = tmp[count - 1:count]
         return [FR(v) for v in _lib.limbs_to_ints(res.cpu().numpy().view(np.uint64))]
 
-    def _divide_linear(self, coef, count, point):
-        """Quotient of p(x) / (x - point), count - 1 coefficients (the remainder p(point) is dropped)."""
-        tmp = coef[:count].clone()
+    def _divide_linear(self, coef, count, point, q):
+        """Quotient of p(x) / (x - point) into q: count - 1 coefficients (the remainder p(point) is dropped; rows of q
+        behind them are not defined)."""
+        tmp = self.buf["dtmp"]
+        tmp[:count] = coef[:count]
         z = int(point) % R
         self.fv.scale_powers(tmp.data_ptr(), count, z, self.st)
         self.fv.scan(tmp.data_ptr(), count, False, True, self.st)              # suffix sums of c_j z^j
-        q = self._zeros(self.n + PAD)
         q[:count - 1] = tmp[1:count]
         zi = pow(z, -1, R)
         self.fv.scale_powers(q.data_ptr(), count - 1, zi, self.st)
@@ -205,7 +213,8 @@ class DevicePlonk:
         k1, k2 = int(K1), int(K2)
 
         # round 1 (round1.py:55-108)
-        wires = [self._blinded(self._interpolate(col), blind[2 * i:2 * i + 2]) for i, col in enumerate(cols)]
+        B = self.buf
+        wires = [self._blinded(self._interpolate(col, B["w%d" % i]), blind[2 * i:2 * i + 2]) for i, col in enumerate(cols)]
         tickets = [self._submit(w, n + 2) for w in wires]
         ea, eb, ec = (self._coset(w, buf) for w, buf in zip(wires, self.work[:3]))   # round 3's coset evaluations of the wires need no challenge: under the MSMs
         for name, t in zip(("a_comm", "b_comm", "c_comm"), tickets):
@@ -217,7 +226,7 @@ class DevicePlonk:
         # round 2 (round2.py:50-86, permutation.py:89-137)
         beta, gamma = tr.challenge_scalar(b"beta"), tr.challenge_scalar(b"gamma")
         be, ga = int(beta), int(gamma)
-        num, den, tmp = self._zeros(n), self._zeros(n), self._zeros(n)
+        num, den, tmp = B["num"][:n], B["den"][:n], B["tmp"][:n]
         sig = [self.evals["s_sigma%d" % k] for k in (1, 2, 3)]
         for j, (col, idc) in enumerate(zip(cols, (1, k1, k2))):
             self._lin(tmp, [col, self.ident], [1, be * idc % R], n, ga)          # w + beta * k * omega^i + gamma
@@ -233,11 +242,11 @@ class DevicePlonk:
         fv.scan(num.data_ptr(), n, True, False, st)                              # prod_{j<=i} num_j
         fv.scan(den.data_ptr(), n, True, True, st)                               # prod_{j>=i} den_j
         den_total = _lib.limbs_to_ints(den[:1].cpu().numpy().view(np.uint64))[0]
-        z_ev = self._zeros(n)
-        z_ev[:1] = _dev(_limbs([1]))
+        z_ev = B["z_ev"][:n]
+        z_ev[:1] = self.ones[:1]
         self._mul(z_ev[1:], num[:n - 1], den[1:], n - 1)                         # z_i = prod_{j<i} num_j / den_j
         self._lin(z_ev[1:], [z_ev[1:]], [pow(den_total, -1, R)], n - 1)
-        z = self._blinded(self._interpolate(z_ev), blind[6:9])
+        z = self._blinded(self._interpolate(z_ev, B["z"]), blind[6:9])
         t_z = self._submit(z, n + 3)
         ez = self._coset(z, self.work[3])                    # likewise under the commitment of z
         ezw = self.work[4]
@@ -259,9 +268,10 @@ class DevicePlonk:
         if bool(tot[3 * n + 6:].any()):
             raise ValueError("constraint polynomial is not divisible by Z_H: circuit or witness is inconsistent")
         t_parts = []
-        for lo, hi in ((0, n), (n, 2 * n), (2 * n, 3 * n + 6)):
-            part = self._zeros(n + PAD)
+        for k, (lo, hi) in enumerate(((0, n), (n, 2 * n), (2 * n, 3 * n + 6))):
+            part = B["t%d" % k]
             part[:hi - lo] = tot[lo:hi]
+            part[hi - lo:].zero_()
             t_parts.append(part)
         for name, comm in zip(("t_lo_comm", "t_mid_comm", "t_hi_comm"), self._commit_many([(t_parts[0], n), (t_parts[1], n), (t_parts[2], n + 6)])):
             setattr(pr, name, comm)
@@ -280,19 +290,19 @@ class DevicePlonk:
         _, l1_zeta, perm_z, perm_s3, r0 = linearisation_scalars(alpha, beta, gamma, zeta, n, self.omega, pr.a_eval, pr.b_eval, pr.c_eval,
                                                                pr.s_sigma1_eval, pr.s_sigma2_eval, pr.z_omega_eval)
         cf = self.coef
-        r_poly = self._zeros(n + PAD)
+        r_poly = B["r_poly"]
         self._lin(r_poly, [cf["q_m"], cf["q_l"], cf["q_r"], cf["q_o"], cf["q_c"], z, cf["s_sigma3"]],
                   [int(pr.a_eval * pr.b_eval), int(pr.a_eval), int(pr.b_eval), int(pr.c_eval), 1, int(perm_z + alpha * alpha * l1_zeta), int(FR(0) - perm_s3)],
                   n + PAD)
         self._lin(r_poly[:1], [r_poly[:1]], [1], 1, int(r0))                     # + (PI(zeta) + r0), PI = 0
         pr.r_eval = self._evaluate(r_poly, n + 3, zeta)
         zeta_n = zeta ** n
-        numer = self._zeros(n + PAD)
+        numer = B["numer"]
         vs = [int(v ** k) for k in range(1, 7)]
         self._lin(numer, [t_parts[0], t_parts[1], t_parts[2], r_poly, wires[0], wires[1], wires[2], cf["s_sigma1"]],
                   [1, int(zeta_n), int(zeta_n * zeta_n), vs[0], vs[1], vs[2], vs[3], vs[4]], n + PAD)
         self._lin(numer, [numer, cf["s_sigma2"]], [1, vs[5]], n + PAD)
-        w_zeta = self._divide_linear(numer, n + 6, zeta)                         # the constant terms only change the dropped remainder
-        w_zeta_omega = self._divide_linear(z, n + 3, zeta * self.omega)
+        w_zeta = self._divide_linear(numer, n + 6, zeta, B["q0"])                # the constant terms only change the dropped remainder
+        w_zeta_omega = self._divide_linear(z, n + 3, zeta * self.omega, B["q1"])
         pr.W_zeta_comm, pr.W_zeta_omega_comm = self._commit_many([(w_zeta, n + 5), (w_zeta_omega, n + 2)])
         return pr
