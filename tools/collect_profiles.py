@@ -53,6 +53,20 @@ def fold(rnd):
     if stats:
         with open(stats[-1]) as f, open(os.path.join(dst, rnd + "_bench_kernel_stats.csv"), "w") as g:
             g.write(f.read())
+    # The summary's average mixes in the starts of the priming / warm-up / timed sequences, where three lanes enter their
+    # accumulate kernels together and each launch lasts twice as long; the launches of the TIMED steps are the last ones.
+    traces = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    if traces:
+        d = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in csv.DictReader(open(traces[-1]))
+                   if "msm_accumulate_kernel" in r["Kernel_Name"] and "Fp2" not in r["Kernel_Name"])
+        timed = [x[1] for x in d[-20:]]
+        bl = json.loads(line)
+        with open(os.path.join(dst, rnd + "_accumulate_launches.json"), "w") as f:
+            json.dump({"kernel": "msm_accumulate_kernel<Fp>", "launches_in_trace": len(d), "avg_ms_all_launches": sum(x[1] for x in d) / len(d),
+                       "timed_steps": len(timed), "avg_ms_timed_steps": sum(timed) / len(timed), "ms_each_launch": [round(x[1], 4) for x in d],
+                       "hip_event_avg_ms_bench_default_run": bl["extra"]["stage_ms"]["accumulate"],
+                       "_note": "from the kernel trace of the rocprofv3 --kernel-trace --stats run (--steps 20 --warmup 4, after 30 clock-priming steps and "
+                                "3 one-point lane-priming launches); bench.py's roofline uses the HIP-event average of its own timed steps"}, f, indent=1)
     rows = []
     per = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
