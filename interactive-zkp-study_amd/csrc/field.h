@@ -16,6 +16,11 @@
 //                     value < va*vb/R + m  (< 2m under the contract).
 //   fe_add            value a+b, normalised.         fe_sub_k<K>: a - b + K*m (needs b <= K*m).
 //   fe_wreduce<M>     value < M*m (M <= 16) -> < 2m.  fe_reduce_full: < 16m -> canonical < m.
+//   fe_sub_lazy<K> / fe_neg_lazy<K>   a - b + (K+1)*m / (K+1)*m - a with NO carry propagation (limbs up to 3 * 2^29):
+//                     only for a value that is used once, as a multiplication operand.
+//   fe_sub2<K>        a - b - 2c + K*m in one pass.   fe_mul_minus<K>: a*b - c out of one reduction (c rides in the
+//                     upper columns of the product).  fe_dot<N> / fe_mulsub<K>: sums of products, one reduction.
+// The accumulate kernel is instruction-issue-bound, so these exist to delete non-multiply instructions.
 // curve.h documents the bound of every intermediate of its formulas against these contracts;
 // tests/hostmath runs the same code on the CPU with ZK_FIELD_DEBUG bound tracking.
 //
