@@ -169,7 +169,9 @@ int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals,
  *                           from the last element down (suffix sums / products).  Synthetic division by (x - z):
  *                           q[i] = z^-(i+1) * sum_{j>i} c[j] z^j;  grand product: prefix products of the numerators
  *                           times suffix products of the denominators over their total.
- * A zk_frvec holds the scratch of the last two (power tables, per-level chunk totals); one per thread of use.
+ * A zk_frvec holds the scratch of the last two (power tables, per-level chunk totals); one per thread and stream of use:
+ * every call rewrites it with kernels on `stream` (nothing is built on the host, no call synchronises), so only stream
+ * order keeps consecutive calls apart.
  */
 /* The PLONK round-3 quotient in one pass (zkp/plonk/prover/round3.py:114-147 builds the numerator by polynomial products and
  * divides by Z_H with poly_div): for every point of the evaluation coset

@@ -19,6 +19,8 @@ void plonk_quotient(void *d_out, const void *const *d_in, const uint64_t *zh_inv
                     const uint64_t gamma[4], size_t n, hipStream_t st);
 
 // Scratch owned by whoever issues the calls (one per thread of use): power tables and the scan's per-level chunk totals.
+// One scratch object serves one stream at a time: its tables and scan levels are rewritten by every call and only stream
+// order keeps an earlier call's kernels ahead of the next call's writes.
 struct FrVecScratch {
     DevBuf tables;
     DevBuf levels[4];  // n <= 2^28: 2^17, 2^6 and 1 chunk totals
