@@ -109,14 +109,14 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32
     }
 }
 
-// One workgroup = 4096 consecutive (window, point) entries of the flat digit array (all of one window row: n_pad is a
-// multiple of 4096).  Ranks them by cell in LDS, reserves the cells' spans and writes the entries out cell by cell;
-// the stored index is the TABLE row  w * stride + first + i  (| sign << 31), so the generic accumulate kernel gathers
-// straight from the table.
-template <int DUMMY>
+// One workgroup = 1024 * PPT consecutive entries of the flat (window-major) digit array.  Ranks them by cell in LDS, reserves
+// the cells' spans and writes the entries out cell by cell; the stored index is the TABLE row  w * stride + first + i
+// (| sign << 31), so the generic accumulate kernel gathers straight from the table.  With 2048 cells a workgroup's share
+// of a cell is only entries / 2048 long: PPT = 8 (8192 entries) gives 16-byte runs and half the cursor atomics of PPT = 4.
+template <int PPT>
 __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int32_t *__restrict__ digits, SortBufs B, uint32_t n_pad, size_t stride,
-                                                                     uint32_t first) {
-    constexpr int NE = PREP_NT * PREP_PPT;
+                                                                     uint32_t first, uint32_t total) {
+    constexpr int NE = PREP_NT * PPT;
     __shared__ uint32_t hist[FIX_G];   // counts, then exclusive offsets
     __shared__ uint32_t gpos[FIX_G];
     __shared__ uint32_t wave_tot[PREP_NT / 64 + 1];
@@ -124,15 +124,15 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
     __shared__ uint16_t stage_cell[NE];
     __shared__ uint8_t stage_loc[NE];
     const uint32_t t = threadIdx.x;
-    const size_t v0 = (size_t)blockIdx.x * NE;
-    const uint32_t w = (uint32_t)(v0 / n_pad), i0 = (uint32_t)(v0 % n_pad);
+    const uint32_t v0 = blockIdx.x * NE;
     for (uint32_t k = t; k < FIX_G; k += PREP_NT) hist[k] = 0;
     __syncthreads();
-    uint32_t rk[PREP_PPT], jj[PREP_PPT];
-    int dd[PREP_PPT];
+    uint32_t rk[PPT], jj[PPT];
+    int dd[PPT];
 #pragma unroll
-    for (int rep = 0; rep < PREP_PPT; rep++) {
-        dd[rep] = digits[v0 + t + rep * PREP_NT];
+    for (int rep = 0; rep < PPT; rep++) {
+        const uint32_t v = v0 + t + rep * PREP_NT;
+        dd[rep] = v < total ? digits[v] : 0;
         jj[rep] = (uint32_t)(dd[rep] < 0 ? -dd[rep] : dd[rep]) - 1u;
         rk[rep] = dd[rep] != 0 ? atomicAdd(&hist[jj[rep] >> SEG_LOG], 1u) : 0u;
     }
@@ -140,26 +140,27 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
     // exclusive scan of the 2048 cell counts: two per thread
     static_assert(FIX_G == 2 * PREP_NT, "two cells per thread");
     const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan<PREP_NT>(h0 + h1, wave_tot, &total);
+    uint32_t total_here;
+    const uint32_t ex = block_exclusive_scan<PREP_NT>(h0 + h1, wave_tot, &total_here);
     hist[2 * t] = ex;
     hist[2 * t + 1] = ex + h0;
     gpos[2 * t] = h0 ? B.cell_base[2 * t] + atomicAdd(&B.cell_cursor[2 * t], h0) : 0u;
     gpos[2 * t + 1] = h1 ? B.cell_base[2 * t + 1] + atomicAdd(&B.cell_cursor[2 * t + 1], h1) : 0u;
     __syncthreads();
 #pragma unroll
-    for (int rep = 0; rep < PREP_PPT; rep++) {
+    for (int rep = 0; rep < PPT; rep++) {
         if (dd[rep] != 0) {
             const uint32_t cellg = jj[rep] >> SEG_LOG;
             const uint32_t p = hist[cellg] + rk[rep];
-            const size_t row = (size_t)w * stride + first + i0 + t + rep * PREP_NT;
+            const uint32_t v = v0 + t + rep * PREP_NT, w = v / n_pad, i = v - w * n_pad;   // a workgroup may straddle two rows
+            const size_t row = (size_t)w * stride + first + i;
             stage_idx[p] = (uint32_t)row | (dd[rep] < 0 ? 0x80000000u : 0u);
             stage_loc[p] = (uint8_t)(jj[rep] & (SEG_BUCKETS - 1));
             stage_cell[p] = (uint16_t)cellg;
         }
     }
     __syncthreads();
-    for (uint32_t p = t; p < total; p += PREP_NT) {
+    for (uint32_t p = t; p < total_here; p += PREP_NT) {
         const uint32_t cellg = stage_cell[p];
         const uint32_t dst = gpos[cellg] + (p - hist[cellg]);
         B.e_idx[dst] = stage_idx[p];

@@ -963,8 +963,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.heavy_th = std::max<uint32_t>(32, 8 * (uint32_t)(((size_t)FIX_W * n_pad) / FIX_NB));
         const PackedAffine<F> *table = fix_table.template as<PackedAffine<F>>();
         hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
-        hipLaunchKernelGGL((msm_fixed_partition_kernel<0>), dim3((unsigned)(((size_t)FIX_W * n_pad) / (PREP_NT * PREP_PPT))), dim3(PREP_NT), 0, ls,
-                           L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first);
+        constexpr int FIX_PPT = 8;
+        const uint32_t fix_total = (uint32_t)FIX_W * n_pad;
+        hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
+                           L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B, FIX_NB);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
