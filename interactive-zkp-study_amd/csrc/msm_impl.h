@@ -492,9 +492,14 @@ __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ 
     // share a SIMD, and those wavefronts hide the gather latency better than a prefetch under three / one did
     // (G1 accumulate 1.30 -> 1.27 ms, G2 4.40 -> 3.63 ms).
     Xyzz<F> acc = Xyzz<F>::inf();
+    // G1 only: the NEXT list entry is fetched one addition ahead (one register), so the gather's address is ready when this
+    // addition ends (accumulate -2 %); the G2 kernel has no register to spare and measured no gain.
+    constexpr bool AHEAD = F::CANON_WORDS == 8;
+    uint32_t e_next = (AHEAD && len) ? lst[0] : 0u;
 #pragma unroll 1
     for (uint32_t k = 0; k < len; k++) {
-        const uint32_t e = lst[k];
+        const uint32_t e = AHEAD ? e_next : lst[k];
+        if (AHEAD && k + 1 < len) e_next = lst[k + 1];
         Affine<F> p = unpack_affine(pts[e & 0x7fffffffu]);
         if (e >> 31) p.y = fe_neg_once<2>(p.y);   // enters one product (or is tidied on the rare paths)
         xyzz_add_affine(acc, p);
