@@ -204,13 +204,9 @@ class ScaleProver:
         for d in (ua, ub, d_c):
             self.ntt.run(d.data_ptr(), True, None, st)
         self.ext_b2[:m].copy_(ub)
-        # the MSMs that do not need H go first (each plan keeps up to three in flight, every one in its own workspace and
-        # stream): they overlap each other, the H pipeline below and the host folds
-        t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
-        t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
-        t_b1 = self._msm(self.g1, self.ext_b1, crs.d_s12, 0, m + 3, st)                  # beta + B(x) in G1
-        t_l = self._msm(self.g1, d_w, crs.d_s14, self.off14, W, st)                      # placeholders at public wires are infinity
-        # H = (A*B - C) / Z on the coset 5*H: 3 coset NTTs + pointwise quotient + 1 coset inverse NTT
+        # H = (A*B - C) / Z on the coset 5*H: 3 coset NTTs + pointwise quotient + 1 coset inverse NTT.  The transforms go
+        # FIRST: an accumulate kernel fills every wavefront slot a CU frees, so NTT workgroups queued behind an MSM would
+        # wait for its whole grid, the H query would start last and finish alone.
         ca.copy_(ua)
         cb.copy_(ub)
         cc.copy_(d_c)
@@ -218,11 +214,17 @@ class ScaleProver:
             self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
-        proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                          # proving.py:23-33
+        # five MSMs, each in its own workspace and stream (the G1 plan keeps three in flight).  The G2 one leads: its long,
+        # latency-bound bucket reduction then runs beside the G1 accumulate kernels instead of alone.
+        t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
+        t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
+        t_b1 = self._msm(self.g1, self.ext_b1, crs.d_s12, 0, m + 3, st)                  # beta + B(x) in G1
         t_h = self._msm(self.g1, h, crs.d_s15, self.off15, m - 1, st)
+        proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                          # proving.py:23-33
+        t_l = self._msm(self.g1, d_w, crs.d_s14, self.off14, W, st)                      # placeholders at public wires are infinity
         msm_b1 = self._pt(self.g1, self.g1.collect_limbs(t_b1))
-        msm_l = self._pt(self.g1, self.g1.collect_limbs(t_l))
         msm_h = self._pt(self.g1, self.g1.collect_limbs(t_h))
+        msm_l = self._pt(self.g1, self.g1.collect_limbs(t_l))
         proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                         # proving.py:35-45
         # proving.py:47-75 with the +-r*s*delta terms cancelled:  s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H
         proof_c = msm_g1([s, r, 1, 1], [proof_a, msm_b1, msm_l, msm_h])
@@ -299,21 +301,21 @@ class ShardedScaleProver(ScaleProver):
             lo, hi = self._slice(total)
             return plan.submit(scal.data_ptr() + 32 * lo, pts.data_ptr() + point_bytes * lo, hi - lo, st)
 
-        t_a = submit(self.g1, self.ext_a, crs.d_s12, m + 3, 64)
-        t_b2 = submit(self.g2, self.ext_b2, crs.d_s22, m + 2, 128)
-        t_b1 = submit(self.g1, self.ext_b1, crs.d_s12, m + 3, 64)
-        t_l = submit(self.g1, d_w, crs.d_s14, W, 64)
-        ca.copy_(ua)
+        ca.copy_(ua)                                                                  # transforms first, the G2 MSM leads: see ScaleProver.prove
         cb.copy_(ub)
         cc.copy_(d_c)
         for d in (ca, cb, cc):
             self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
-        p_a = self.g1.collect_partial(t_a)
+        t_b2 = submit(self.g2, self.ext_b2, crs.d_s22, m + 2, 128)
+        t_a = submit(self.g1, self.ext_a, crs.d_s12, m + 3, 64)
+        t_b1 = submit(self.g1, self.ext_b1, crs.d_s12, m + 3, 64)
         t_h = submit(self.g1, h, crs.d_s15, m - 1, 64)
-        mine = np.concatenate([p_a, self.g1.collect_partial(t_b1), self.g1.collect_partial(t_l), self.g1.collect_partial(t_h),
-                               self.g2.collect_partial(t_b2)])                       # 4 * 16 + 32 limbs
+        p_a = self.g1.collect_partial(t_a)
+        t_l = submit(self.g1, d_w, crs.d_s14, W, 64)
+        p_b1, p_h, p_l = self.g1.collect_partial(t_b1), self.g1.collect_partial(t_h), self.g1.collect_partial(t_l)
+        mine = np.concatenate([p_a, p_b1, p_l, p_h, self.g2.collect_partial(t_b2)])    # 4 * 16 + 32 limbs
         everyone = all_gather_partials(mine, device=self.device, group=self.group)  # (world, 96)
         g1_parts = [fold_partials(_lib.GROUP_G1, np.ascontiguousarray(everyone[:, 16 * k:16 * (k + 1)])) for k in range(4)]
         proof_a, msm_b1, msm_l, msm_h = g1_parts
