@@ -7,8 +7,12 @@ are already resident in HBM (BASELINE.json configs[1]); with --gpus N every rank
 partials are combined by one RCCL all-gather + host fold per step (zkhip.distributed).
 
     python bench.py                       # 1 GPU
+    python bench.py --gpus N              # N GPUs: starts N ranks itself (torch.distributed.run children, before this
+                                          #   process touches a GPU), relays rank 0's line, exits with the children's code;
+                                          #   fails if fewer than N devices are visible (--rehearse: ranks share the
+                                          #   visible devices over gloo -- a correctness rehearsal, not a measurement)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # the same ranks, launched by the caller
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      dominant kernel (bucket accumulation): algorithmic bytes (96 B/point) / its average
@@ -20,6 +24,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
 import argparse, ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,40 +34,47 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
 
-R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 HBM_PEAK_GBS = 8000.0
 G1_BYTES_PER_POINT = 96  # 32 B scalar + 64 B affine point, each read once
+MADS_PER_MADD = 1467     # v_mad_u64_u32 in one XYZZ += affine addition as compiled (code object of msm_accumulate_kernel<Fp>)
 
 
-def random_scalars(rng, n):
-    """Uniform in [0, r): 254-bit rejection sampling -> (n, 4) uint64 limbs."""
-    out = np.empty((n, 4), dtype=np.uint64)
-    r_limbs = [(R_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
-    filled = 0
-    while filled < n:
-        m = int((n - filled) * 1.4) + 16
-        cand = rng.integers(0, 1 << 64, size=(m, 4), dtype=np.uint64)
-        cand[:, 3] &= np.uint64((1 << 62) - 1)
-        lt = np.zeros(m, dtype=bool)
-        eq = np.ones(m, dtype=bool)
-        for i in (3, 2, 1, 0):
-            lt |= eq & (cand[:, i] < np.uint64(r_limbs[i]))
-            eq &= cand[:, i] == np.uint64(r_limbs[i])
-        good = cand[lt]
-        take = min(len(good), n - filled)
-        out[filled:filled + take] = good[:take]
-        filled += take
-    return out
+from zkhip.synthetic import (R_MOD, arithmetic_dot, arithmetic_dot_device, arithmetic_points, fixed_base_points,  # noqa: E402
+                             limbs_dot_mod_r, random_scalars, random_scalars_device)
 
 
-def limbs_dot_mod_r(a, b):
-    """sum_i a_i * b_i mod r on Python ints (closed-form MSM check)."""
-    from zkhip import _lib
-    ai, bi = _lib.limbs_to_ints(a), _lib.limbs_to_ints(b)
-    acc = 0
-    for x, y in zip(ai, bi):
-        acc += x * y
-    return acc % R_MOD
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_command(argv, n_ranks, port):
+    """The child command of `bench.py --gpus N`: one rank per GPU under torch.distributed.run, same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` with no rank environment: start the N ranks as children of this process, which has not made
+    (and never makes) a HIP call -- torch.cuda.device_count() only reads the device list -- and relay their output."""
+    import torch
+    visible = torch.cuda.device_count()
+    if args.dry_launch:
+        print(json.dumps({"launch": launch_command(argv, args.gpus, 0), "visible_devices": visible}), flush=True)
+        return 0
+    if visible < args.gpus and not args.rehearse:
+        sys.stderr.write("bench.py: --gpus %d needs %d HIP devices, %d visible (use --rehearse to let the ranks share them over gloo)\n"
+                         % (args.gpus, args.gpus, visible))
+        return 2
+    if visible < 1:
+        sys.stderr.write("bench.py needs a HIP device (there is no CPU fallback)\n")
+        return 2
+    cmd = launch_command(argv, args.gpus, _free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -80,7 +93,16 @@ def main():
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
     ap.add_argument("--dist-ntt-log-n", type=int, default=24, help="N > 1 only: log2 size of the single NTT spread over all GPUs (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
+    ap.add_argument("--rehearse", action="store_true", help="N > 1 with fewer than N devices: the ranks share the visible devices and talk over gloo "
+                    "(checks the N-rank code path; the numbers are not a scaling measurement)")
+    ap.add_argument("--dry-launch", action="store_true", help="N > 1: print the child command instead of running it")
+    ap.add_argument("--sizes", default="24,26", help="N = 1: log2 sizes of the extra one-GPU G1 MSM measurements (BASELINE.json metric names 2^20/2^24/2^26; '' = skip)")
+    ap.add_argument("--sizes-ntt", default="24", help="N = 1: log2 sizes of the extra NTT measurements ('' = skip)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -92,17 +114,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    visible = torch.cuda.device_count()
+    if visible < world and not args.rehearse:
+        raise SystemExit("bench.py: %d ranks but %d HIP devices visible (one process per GPU; --rehearse shares devices over gloo)" % (world, visible))
+    rehearsal = args.rehearse and visible < world
+    dev_index = local_rank % visible
+    torch.cuda.set_device(dev_index)
     lib = _lib.load()
-    _lib.check(lib.zk_set_device(local_rank))
-    dev = torch.device("cuda", local_rank)
+    _lib.check(lib.zk_set_device(dev_index))
+    dev = torch.device("cuda", dev_index)
     dist_on = world > 1 or args.force_dist
+    # collectives: RCCL ("nccl") between GPUs; gloo when ranks share a device (RCCL refuses two ranks on one GPU), in which
+    # case the few bytes of every exchange are staged through the host (zkhip.distributed handles both)
+    cdev = None if rehearsal else dev                                  # where control tensors and partials live
     if dist_on:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()                                  # n_gpus of the line = what the process group reports
     n = 1 << args.log_n
 
     # ---- synthetic workload, generated once and left resident in HBM
@@ -127,7 +163,7 @@ def main():
     def finish(ticket):
         if not dist_on:
             return plan.collect_limbs(ticket)
-        return sharded_msm(_lib.GROUP_G1, plan.collect_partial(ticket), device=dev)
+        return sharded_msm(_lib.GROUP_G1, plan.collect_partial(ticket), device=cdev)
 
     depth = plan.max_in_flight() if n <= (1 << 22) else 1   # larger MSMs already run as 2^22-point chunks through all lanes
 
@@ -162,7 +198,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     stage /= max(args.steps, 1)
@@ -188,25 +224,22 @@ def main():
     # Every rank joins in (collectives inside); any failure is reported on every rank alike before the collectives start.
     if dist_on and args.shard_total_log:
         try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from bench_sizes import arithmetic_dot, arithmetic_points
             from zkhip.distributed import shard_range
             n_tot = 1 << args.shard_total_log
             lo, hi = shard_range(n_tot, rank, world)
             m_loc = hi - lo
-            k0, dd = 0x1234567890ABCDEF >> 1, 0x9E3779B1
-            s_loc = random_scalars(np.random.default_rng(0x5EEDB260 + rank), m_loc)
-            p_loc = arithmetic_points(lib, m_loc, k0 + lo * dd, dd)          # P_i = (k0 + i d) G for the global index i
-            d_s2 = torch.from_numpy(s_loc.view(np.int64)).to(dev)
+            d_s2 = random_scalars_device(m_loc, dev, 0x5EEDB260 + rank)
+            p_loc = arithmetic_points(lib, m_loc, first=lo)                  # P_i = (k0 + i d) G for the global index i
             d_p2 = torch.from_numpy(p_loc.view(np.int64)).to(dev)
+            del p_loc
             plan2 = MsmPlan(_lib.GROUP_G1, m_loc)
-            ok_all = torch.ones(1, device=dev)
+            ok_all = torch.ones(1, device=cdev)
         except Exception as exc:                                              # noqa: BLE001 -- keep the ranks in step
-            ok_all = torch.zeros(1, device=dev)
+            ok_all = torch.zeros(1, device=cdev)
             shard_err = repr(exc)
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
         if float(ok_all.item()) == 1.0:
-            one = lambda: sharded_msm(_lib.GROUP_G1, plan2.run_partial(d_s2.data_ptr(), d_p2.data_ptr(), m_loc, stream), device=dev)
+            one = lambda: sharded_msm(_lib.GROUP_G1, plan2.run_partial(d_s2.data_ptr(), d_p2.data_ptr(), m_loc, stream), device=cdev)
             one()
             fence()
             t_s = time.perf_counter()
@@ -216,7 +249,7 @@ def main():
             fence()
             sms = (time.perf_counter() - t_s) / sreps * 1e3
             dots = [None] * world
-            dist.all_gather_object(dots, arithmetic_dot(s_loc, k0 + lo * dd, dd))
+            dist.all_gather_object(dots, arithmetic_dot_device(d_s2, first=lo))
             extra["sharded_one_msm"] = {"log_n_total": args.shard_total_log, "points_per_gpu": m_loc, "ms_per_msm": round(sms, 3),
                                         "points_per_s": n_tot / (sms * 1e-3), "verified_closed_form": bool(got_tot == ec_mul(G1, sum(dots) % R_MOD))}
             plan2.close()
@@ -278,7 +311,7 @@ def main():
         ms = e0.elapsed_time(e1) / (2 * reps)  # per transform, this rank's device time
         exact = bool(torch.equal(d, ref))
         if dist_on:
-            tt = torch.tensor([span, 0.0 if exact else 1.0], dtype=torch.float64, device=dev)
+            tt = torch.tensor([span, 0.0 if exact else 1.0], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             span, exact = float(tt[0].item()), float(tt[1].item()) == 0.0
         extra["ntt"] = {"log_n": L, "ms_per_transform": round(ms, 4), "elements_per_s": m / (ms * 1e-3),
@@ -330,7 +363,7 @@ def main():
             except Exception as exc:  # noqa: BLE001 -- a secondary measurement must not take the headline line down with it
                 dn = None
                 sys.stderr.write("dist_ntt set-up failed on rank %d: %r\n" % (rank, exc))
-            ready = torch.tensor([1.0 if dn is not None else 0.0], dtype=torch.float64, device=dev)
+            ready = torch.tensor([1.0 if dn is not None else 0.0], dtype=torch.float64, device=cdev)
             dist.all_reduce(ready, op=dist.ReduceOp.MIN)
             if float(ready.item()) == 1.0:
                 x = x0.clone()
@@ -345,7 +378,7 @@ def main():
                     x = y if dn.l1 == dn.l2 else x0.clone()     # even log n: the output layout is the input layout again
                 fence()
                 dms = (time.perf_counter() - td0) / dreps * 1e3
-                tt = torch.tensor([dms, 0.0 if ok_rt else 1.0], dtype=torch.float64, device=dev)
+                tt = torch.tensor([dms, 0.0 if ok_rt else 1.0], dtype=torch.float64, device=cdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 extra["dist_ntt"] = {"log_n": args.dist_ntt_log_n, "ms_per_forward": round(float(tt[0].item()), 4),
                                      "elements_per_s": (1 << args.dist_ntt_log_n) / (float(tt[0].item()) * 1e-3), "roundtrip_exact": float(tt[1].item()) == 0.0}
@@ -374,6 +407,64 @@ def main():
                                  "stage_ms": [round(v, 4) for v in plan.stage_ms()]}
         del d_wl
 
+    # ---- secondary, N = 1: the other sizes BASELINE.json's metric names (2^24, 2^26 points on ONE GPU; blocking calls, closed-form
+    # verified) and the 2^24-point NTT north_star names.  Inputs are generated outside the timed calls and resident in HBM.
+    if rank == 0 and world == 1 and not dist_on and (args.sizes or args.sizes_ntt):
+        sizes = {"msm_g1": [], "ntt": []}
+        for L in [int(v) for v in args.sizes.split(",") if v]:
+            try:
+                nn = 1 << L
+                d_s = random_scalars_device(nn, dev, 0x5EEDB300 + L)
+                d_p = torch.from_numpy(arithmetic_points(lib, nn).view(np.int64)).to(dev)       # P_i = (k0 + i d) G1
+                pl = MsmPlan(_lib.GROUP_G1, nn)
+                pl.set_profiling(True)
+                res = pl.run(d_s.data_ptr(), d_p.data_ptr(), nn, stream)
+                ts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    res = pl.run(d_s.data_ptr(), d_p.data_ptr(), nn, stream)
+                    ts.append(time.perf_counter() - t0_)
+                ms_ = min(ts) * 1e3
+                acc_ms_ = pl.stage_ms()[2]
+                chunk = min(nn, 1 << 22)                                      # larger MSMs run as 2^22-point chunks through the lanes
+                gbs = G1_BYTES_PER_POINT * chunk / (acc_ms_ * 1e-3) / 1e9 if acc_ms_ > 0 else 0.0
+                sizes["msm_g1"].append({"log_n": L, "ms_per_msm_blocking": round(ms_, 3), "points_per_s": nn / (ms_ * 1e-3),
+                                        "accumulate_ms_last_chunk": round(acc_ms_, 4), "chunk_points": chunk, "chunks": nn // chunk,
+                                        "accumulate_GBps": gbs, "accumulate_hbm_frac": gbs / HBM_PEAK_GBS,
+                                        "verified_closed_form": bool(res == ec_mul(G1, arithmetic_dot_device(d_s)))})
+                pl.close()
+                del d_s, d_p, pl
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001 -- a secondary measurement must not take the headline line down with it
+                sizes["msm_g1"].append({"log_n": L, "error": repr(exc)})
+        for L in [int(v) for v in args.sizes_ntt.split(",") if v]:
+            try:
+                mm = 1 << L
+                d = random_scalars_device(mm, dev, 0x5EEDB340 + L)
+                ref = d.clone()
+                npl = NttPlan(L)
+                npl.run(d.data_ptr(), False, None, stream)
+                npl.run(d.data_ptr(), True, None, stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                nreps = 4
+                e0.record()
+                for _ in range(nreps):
+                    npl.run(d.data_ptr(), False, None, stream)
+                    npl.run(d.data_ptr(), True, None, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                ms_ = e0.elapsed_time(e1) / (2 * nreps)
+                sizes["ntt"].append({"log_n": L, "ms_per_transform": round(ms_, 4), "elements_per_s": mm / (ms_ * 1e-3),
+                                     "algorithmic_GBps": 64.0 * mm / (ms_ * 1e-3) / 1e9, "hbm_frac": 64.0 * mm / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "roundtrip_exact": bool(torch.equal(d, ref))})
+                npl.close()
+                del d, ref, npl
+                torch.cuda.empty_cache()
+            except Exception as exc:  # noqa: BLE001
+                sizes["ntt"].append({"log_n": L, "error": repr(exc)})
+        extra["sizes"] = sizes
+
     # ---- the integer-ALU ceiling the MSM is really priced against (row D3): this library's own field
     # multiplication / mixed addition run flat out on the whole chip, measured live
     alu = None
@@ -383,12 +474,18 @@ def main():
         modmul_peak = rate.value
         _lib.check(lib.zk_measure_rate(1, ctypes.byref(rate)))
         madd_peak = rate.value
+        _lib.check(lib.zk_measure_rate(2, ctypes.byref(rate)))
+        mad_rate = rate.value
         W = -(-255 // plan.window_bits(n))
         madds = float(n) * W  # one mixed addition per (point, window) digit; zero digits (2^-c of them) are skipped
         acc_s = float(stage[2]) * 1e-3
         alu = {"unit": "G1 mixed additions/s", "per_launch": madds, "achieved": madds / acc_s if acc_s > 0 else 0.0, "peak": madd_peak,
                "frac": (madds / acc_s / madd_peak) if acc_s > 0 else 0.0, "modmul_peak_per_s": modmul_peak,
-               "modmul_per_madd": 10, "note": "peak = zk_measure_rate(1): dependent XYZZ+=affine chains, one wave per workgroup, chip oversubscribed"}
+               "modmul_per_madd": 10, "note": "peak = zk_measure_rate(1): dependent XYZZ+=affine chains, one wave per workgroup, chip oversubscribed",
+               # the ceiling that does not depend on this library's arithmetic: the chip's v_mad_u64_u32 issue rate (zk_measure_rate(2): bare
+               # independent multiply-adds, as tools/ubench.hip) against the multiply-adds one mixed addition compiles to
+               "mad_floor": {"v_mad_u64_u32_lane_ops_per_s": mad_rate, "mads_per_madd": MADS_PER_MADD, "floor_ms": madds * MADS_PER_MADD / mad_rate * 1e3,
+                             "frac": (madds * MADS_PER_MADD / mad_rate) / acc_s if acc_s > 0 else 0.0}}
 
     # ---- secondary: Groth16 prove() wall-clock on a synthetic 2^20-constraint R1CS (BASELINE.json configs[3])
     if args.groth16_log_m and world == 1:
@@ -463,6 +560,8 @@ def main():
             "cpu_baseline": cpu,
             "extra": extra,
         }
+        if dist_on:
+            line["config"]["collectives"] = "gloo, ranks share %d device(s): REHEARSAL, not a scaling measurement" % visible if rehearsal else "RCCL (nccl backend)"
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

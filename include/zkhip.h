@@ -221,7 +221,9 @@ int zk_pairing_check(const uint64_t *g1_points /* n*8 */, const uint64_t *g2_poi
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): chip-wide rate of the library's own arithmetic,
  * the integer-ALU ceiling bench.py prices the MSM against.
- *   what = 0: Montgomery multiplications in F_p per second;  1: G1 mixed (XYZZ += affine) additions per second.
+ *   what = 0: Montgomery multiplications in F_p per second;  1: G1 mixed (XYZZ += affine) additions per second;
+ *   what = 2: bare v_mad_u64_u32 lane-operations per second (independent chains, nothing else in the loop) -- the
+ *             hardware multiply-add issue rate, a ceiling that does not depend on this library's field arithmetic.
  */
 int zk_measure_rate(int what, double *out_per_sec);
 

@@ -144,9 +144,29 @@ __global__ __launch_bounds__(64, 3) void rate_madd_kernel(const uint32_t *gen_xy
     if (blockIdx.x * 64 + threadIdx.x == sink_thread) out[0] = acc;
 }
 
+// The chip's bare v_mad_u64_u32 issue rate: four independent accumulator chains per thread, nothing else in the loop
+// (the probe of tools/ubench.hip).  This ceiling does not depend on how field.h arranges a modular product.
+__global__ __launch_bounds__(256) void rate_mad_kernel(uint32_t *out, int iters, uint32_t sink_thread) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t a = i * 2654435761u + 12345u, b = a ^ 0x9e3779b9u;
+    uint64_t q0 = a, q1 = b, q2 = a + 3, q3 = b + 5;
+#pragma unroll 1
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %4, %5, %1\n"
+                         "v_mad_u64_u32 %2, vcc, %4, %5, %2\n v_mad_u64_u32 %3, vcc, %4, %5, %3"
+                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)
+                         : "v"(a), "v"(b)
+                         : "vcc");
+    }
+    const uint64_t x = q0 ^ q1 ^ q2 ^ q3;
+    if (i == sink_thread) out[0] = (uint32_t)x ^ (uint32_t)(x >> 32);
+}
+
 static int measure_rate(int what, double *out_per_sec) {
     if (!out_per_sec) return invalid("zk_measure_rate: null output");
-    const int iters = what == 0 ? 512 : 96;
+    const int iters = what == 0 ? 512 : what == 1 ? 96 : 2048;
     DevBuf sink(sizeof(Xyzz<Fp>)), gen(64);
     const uint64_t g[8] = {1, 0, 0, 0, 2, 0, 0, 0};
     ZK_HIP(hipMemcpy(gen.p, g, 64, hipMemcpyHostToDevice));
@@ -159,6 +179,10 @@ static int measure_rate(int what, double *out_per_sec) {
             const unsigned blocks = 256 * 16;
             hipLaunchKernelGGL(rate_modmul_kernel, dim3(blocks), dim3(256), 0, 0, sink.as<Fp>(), iters, 0xffffffffu);
             units = (double)blocks * 256 * iters * 2;
+        } else if (what == 2) {
+            const unsigned blocks = 256 * 8;
+            hipLaunchKernelGGL(rate_mad_kernel, dim3(blocks), dim3(256), 0, 0, sink.as<uint32_t>(), iters, 0xffffffffu);
+            units = (double)blocks * 256 * iters * 32;
         } else {
             const unsigned blocks = 256 * 4 * 12;  // the accumulate kernel's shape: one wave per workgroup
             hipLaunchKernelGGL(rate_madd_kernel, dim3(blocks), dim3(64), 0, 0, gen.as<uint32_t>(), sink.as<Xyzz<Fp>>(), iters, 0xffffffffu);
@@ -398,7 +422,7 @@ int zk_measure_rate(int what, double *out_per_sec) {
     return guarded([&]() -> int {
         int rc = require_device();
         if (rc) return rc;
-        if (what != 0 && what != 1) return invalid("zk_measure_rate: what must be 0 (F_p multiplications) or 1 (G1 mixed additions)");
+        if (what < 0 || what > 2) return invalid("zk_measure_rate: what must be 0 (F_p multiplications), 1 (G1 mixed additions) or 2 (v_mad_u64_u32)");
         return measure_rate(what, out_per_sec);
     });
 }

@@ -43,30 +43,7 @@ def limb_row(v):
     return co.to_limbs([v])[0]
 
 
-def arithmetic_g1_points(lib, n, k0, d):
-    """P_i = (k0 + i*d) * G1 for i < n with k0 < 2^63, d < 2^32 (no reduction mod r needed): generated by the backend's
-    fixed-base batch from scalars built in numpy -- for sizes where per-point oracle work is out of reach."""
-    from zkhip import _lib
-    i = np.arange(n, dtype=np.uint64)
-    K = np.zeros((n, 4), dtype=np.uint64)
-    K[:, 0] = np.uint64(k0) + i * np.uint64(d)
-    base = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
-    P = np.zeros((n, 8), dtype=np.uint64)
-    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(base), _lib.ptr(K), n, _lib.ptr(P)))
-    return P
-
-
-def arithmetic_dot(S, k0, d):
-    """sum_i s_i * (k0 + i*d) mod r without per-element big integers (16-bit pieces of s, blockwise uint64 sums)."""
-    n = S.shape[0]
-    pieces = S.view(np.uint16).reshape(n, 16).astype(np.uint64)
-    sum_s, sum_is = 0, 0
-    for lo in range(0, n, 1 << 20):
-        pc = pieces[lo:lo + (1 << 20)]
-        idx = np.arange(lo, lo + pc.shape[0], dtype=np.uint64)
-        cs = pc.sum(axis=0, dtype=np.uint64)
-        cis = (pc * idx[:, None]).sum(axis=0, dtype=np.uint64)
-        for j in range(16):
-            sum_s += int(cs[j]) << (16 * j)
-            sum_is += int(cis[j]) << (16 * j)
-    return (k0 * sum_s + d * sum_is) % pr.R
+# P_i = (k0 + i*d) * G1 and sum_i s_i * (k0 + i*d) mod r for sizes where per-point oracle work is out of reach: one
+# implementation, shared with bench.py and tools/ (zkhip/synthetic.py); its host and device forms are checked against
+# Python big integers in tests/test_bench_launcher.py.
+from zkhip.synthetic import arithmetic_dot, arithmetic_points as arithmetic_g1_points  # noqa: E402,F401

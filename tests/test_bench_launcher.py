@@ -1,0 +1,70 @@
+"""CPU tests of bench.py's own launcher (`python bench.py --gpus N` with no rank environment) and of the
+synthetic-workload helpers it uses.  No GPU: the launcher decides before any HIP call."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + list(argv), capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_gpus_2_takes_the_launcher_path():
+    """--gpus 2 without WORLD_SIZE must go through launch_ranks: here (no device) it refuses with exit code 2 and names the
+    device count -- a run that ignored --gpus would instead die on 'needs a HIP device' from the single-rank path."""
+    r = _run("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 2
+    assert "needs 2 HIP devices, 0 visible" in r.stderr
+
+
+def test_dry_launch_prints_one_rank_per_gpu_command():
+    r = _run("--gpus", "4", "--steps", "3", "--warmup", "2", "--dry-launch")
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = rec["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    tail = cmd[cmd.index("--master-port") + 3:]
+    assert tail[:6] == ["--gpus", "4", "--steps", "3", "--warmup", "2"]
+
+
+def test_rank_environment_skips_the_launcher_and_checks_world_size():
+    """Started by the driver's torch.distributed.run the script is a rank, not a launcher; a world size that disagrees
+    with --gpus is an error (before any GPU call)."""
+    r = _run("--gpus", "2", env_extra={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "--gpus 2 but the launcher started 4 ranks" in (r.stderr + r.stdout)
+
+
+def test_single_gpu_without_device_fails_loudly():
+    r = _run("--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "needs a HIP device" in (r.stderr + r.stdout)
+
+
+def test_arithmetic_dot_host_and_device_agree_with_big_integers():
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
+    from zkhip import _lib, synthetic as sy
+    rng = np.random.default_rng(11)
+    s = sy.random_scalars(rng, 70000)
+    ints = _lib.limbs_to_ints(s)
+    assert max(ints) < sy.R_MOD
+    for first in (0, (1 << 25) + 7, (1 << 29) + 12345):
+        want = sum(v * (sy.ARITH_K0 + (first + i) * sy.ARITH_D) for i, v in enumerate(ints)) % sy.R_MOD
+        assert sy.arithmetic_dot(s, first=first) == want
+        assert sy.arithmetic_dot_device(torch.from_numpy(s.view(np.int64)), first=first) == want
+    d = sy.random_scalars_device(50000, "cpu", 5)
+    vals = _lib.limbs_to_ints(d.numpy().view(np.uint64))
+    assert max(vals) < sy.R_MOD and max(vals).bit_length() >= 252 and len(set(vals)) == len(vals)

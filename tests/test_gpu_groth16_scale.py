@@ -52,6 +52,29 @@ def test_scale_prover_closed_form(log_m):
         assert hc[:len(q)] == q
 
 
+def test_scale_prover_2pow20_constraints_closed_form():
+    """BASELINE.json configs[3] at its full size: Groth16 prove() on a synthetic 2^20-constraint R1CS, witness resident in HBM
+    -> (A, B, C), against the closed-form scalars of the known toxic waste; the CRS queries are bound to the MSM plans as
+    bench.py does, and a second proof from the same prover must be identical (no state leaks between proofs)."""
+    import torch
+    log_m = 20
+    circ = ChainCircuit(log_m, seed=7)
+    w, a, b, c = circ.witness()
+    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 201))
+    prover = ScaleProver(crs)
+    prover.load_r1cs(circ.r1cs_csr())
+    d_w = _dev(w)
+    r, s = 4106, 4565
+    pa, pb, pc, h = prover.prove_from_witness(d_w, r, s)
+    A, B, C = closed_form_scalars(crs, w, r, s)
+    assert pa == ec_mul(G1, A)
+    assert pb == ec_mul(G2, B)
+    assert pc == ec_mul(G1, C)
+    torch.cuda.synchronize()
+    assert torch.equal(prover.abc[0], _dev(a)) and torch.equal(prover.abc[1], _dev(b))   # A.w and B.w of the device mat-vec
+    assert (pa, pb, pc) == prover.prove_from_witness(d_w, r, s)[:3]
+
+
 def _sharded_worker(rank, world, port, log_m, ret):
     import os
     import sys

@@ -375,6 +375,37 @@ def test_g1_msm_2pow24_chunked_closed_form():
     plan.close()
 
 
+def test_g1_msm_2pow26_one_gpu_closed_form():
+    """BASELINE.json's largest size (configs[4] is this MSM sharded over eight GPUs) on ONE GPU: sixteen 2^22-point chunks
+    through the plan's lanes, ~7 GB of inputs.  Scalars are drawn on the device (uniform below r), bases are
+    P_i = (k0 + i d) G1, the result must be (sum s_i (k0 + i d)) G1 computed by the oracle; a few bases and the first
+    scalars' canonicity are spot-checked on the host.  The eight-rank split of the same MSM is a sum of such partials:
+    the second half checks that two half-size partial sums fold to the same point (zk_msm_fold_partials)."""
+    import torch
+    from zkhip.distributed import fold_partials
+    from zkhip.synthetic import ARITH_D, ARITH_K0, arithmetic_dot_device, arithmetic_points, random_scalars_device
+    n = 1 << 26
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    dS = random_scalars_device(n, dev, 26)
+    head = _lib.limbs_to_ints(dS[:4096].cpu().numpy().view(np.uint64))
+    assert max(head) < o.R and len(set(head)) == len(head)
+    Pts = arithmetic_points(lib, n)
+    for i in (0, 1, n // 3, n - 1):
+        assert np.array_equal(Pts[i], co.g1_to_arr([co.g1_mul(o.G1, ARITH_K0 + i * ARITH_D)])[0])
+    dP = torch.from_numpy(Pts.view(np.int64)).to(dev)
+    del Pts
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    want = o_point(co.g1_mul(o.G1, arithmetic_dot_device(dS)))
+    assert plan.run(dS.data_ptr(), dP.data_ptr(), n, st) == want
+    half = n // 2
+    parts = np.stack([plan.run_partial(dS[:half].data_ptr(), dP[:half].data_ptr(), half, st),
+                      plan.run_partial(dS[half:].data_ptr(), dP[half:].data_ptr(), half, st)])
+    assert fold_partials(_lib.GROUP_G1, parts) == want
+    plan.close()
+
+
 def o_point(pt):
     from zkhip.field import FQ
     return None if pt is None else (FQ(pt[0]), FQ(pt[1]))

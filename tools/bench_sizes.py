@@ -9,33 +9,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "interactive-zkp
 from bench import random_scalars, limbs_dot_mod_r, R_MOD
 
 
-def arithmetic_points(lib, n, k0, d):
-    """P_i = (k0 + i*d) * G1 with k0 < 2^63, d < 2^32 (no reduction mod r needed): limbs built in numpy."""
-    i = np.arange(n, dtype=np.uint64)
-    K = np.zeros((n, 4), dtype=np.uint64)
-    K[:, 0] = np.uint64(k0) + i * np.uint64(d)          # < 2^63 + 2^58: no wrap
-    base = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
-    P = np.zeros((n, 8), dtype=np.uint64)
-    from zkhip import _lib
-    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(base), _lib.ptr(K), n, _lib.ptr(P)))
-    return P
-
-
-def arithmetic_dot(S, k0, d):
-    """sum_i s_i * (k0 + i*d) mod r without per-element big integers: 16-bit pieces of s, blockwise uint64 sums."""
-    n = S.shape[0]
-    pieces = S.view(np.uint16).reshape(n, 16).astype(np.uint64)      # little-endian 16-bit pieces
-    sum_s, sum_is = 0, 0
-    blk = 1 << 20
-    for lo in range(0, n, blk):
-        pc = pieces[lo:lo + blk]
-        idx = np.arange(lo, lo + pc.shape[0], dtype=np.uint64)
-        cs = pc.sum(axis=0, dtype=np.uint64)                          # < 2^36
-        cis = (pc * idx[:, None]).sum(axis=0, dtype=np.uint64)        # < 2^16 * 2^26 * 2^20 = 2^62
-        for j in range(16):
-            sum_s += int(cs[j]) << (16 * j)
-            sum_is += int(cis[j]) << (16 * j)
-    return (k0 * sum_s + d * sum_is) % R_MOD
+from zkhip.synthetic import arithmetic_dot, arithmetic_points  # noqa: E402
 
 
 def main():
