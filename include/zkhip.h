@@ -14,7 +14,16 @@
  *   - Point at infinity (Python None): all coordinate limbs zero ((0,0) is on neither curve).
  *     Outputs additionally report it through *out_is_inf.
  *   - Scalars must be canonical (< r).  The reference reduces mod r before multiplying
- *     (zkp/plonk/field.py:86-88); the Python layer does the same before calling in.
+ *     (zkp/plonk/field.py:86-88); the Python layer does the same before calling in.  Host-buffer
+ *     entry points check it (ZK_ERR_INVALID).  "_dev" entry points cannot read device memory on the host:
+ *     an MSM over device scalars is exact for every canonical scalar (and any value below 2^254 - 2^240) and
+ *     is never silently wrong above: a scalar whose signed digits do not fit the windows (from 2^255; from
+ *     about 2^254 for plans of at most 2^17 points) is detected on the device, and the call that collects that submission fails with
+ *     ZK_ERR_INVALID and no result; F_r vector / NTT kernels require canonical
+ *     device elements as a precondition.  Host-side scalar arguments (coset_shift, zinv, coefficients)
+ *     are always checked.
+ *   - A plan (zk_msm_plan, zk_ntt_plan) lives on the device that was current when it was created
+ *     (zk_set_device); calls made while another device is current fail with ZK_ERR_INVALID.
  *   - Ownership: the caller allocates and frees every buffer it passes.  The library owns only
  *     the handles it returns (zk_*_create / zk_*_destroy).
  *   - Errors: 0 = ZK_OK, negative = failure; zk_last_error() returns a thread-local message.
@@ -211,6 +220,10 @@ int zk_group_op(int group, int op, const uint64_t *p, const uint64_t *q_or_scala
  * Pairings for the verifiers -- HOST code (a proof needs 2-4 pairings; never a GPU target).
  * Replace py_ecc.bn128.pairing(Q, P) as used by zkp/groth16/verifying.py:17-40,
  * zkp/plonk/field.py:118-138 and zkp/plonk/kzg.py:117-160.  Infinity inputs give the identity.
+ * Like py_ecc's pairing (which asserts is_on_curve for both arguments) every input must be a canonical
+ * point of its curve -- G1: y^2 = x^3 + 3, G2: the twist y^2 = x^3 + 3/(9+i) -- or the all-zero infinity
+ * encoding; anything else fails with ZK_ERR_INVALID before any arithmetic (the reference raises
+ * AssertionError).  As in the reference, subgroup membership of a twist point is not tested.
  *   zk_pairing        e(P, Q) as 12 canonical F_p coefficients (4 limbs each) of
  *                     F_p[w]/(w^12 - 18 w^6 + 82), the reference's FQ12 coefficient order.
  *   zk_pairing_check  *out_is_one = [ prod_i e(P_i, Q_i) == 1 ]  (one shared final exponentiation).
@@ -226,6 +239,13 @@ int zk_pairing_check(const uint64_t *g1_points /* n*8 */, const uint64_t *g2_poi
  *             hardware multiply-add issue rate, a ceiling that does not depend on this library's field arithmetic.
  */
 int zk_measure_rate(int what, double *out_per_sec);
+
+/* ------------------------------------------------------------------------------------------
+ * Test hook (no reference counterpart; not for production use): MSM plans created after this call split
+ * inputs into chunks of 2^log2_points points (12..24) instead of 2^22, so that the chunked path can be
+ * exercised at sizes an oracle can check.  0 restores the default.  Process-wide.
+ */
+int zk_test_set_msm_chunk_log(int log2_points);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" surface of libzkhip.so (declared in include/zkhip.h).
 #include <string.h>
+#include <map>
 #include <memory>
 #include <vector>
 #include "common.h"
@@ -22,6 +23,31 @@ int require_device() {
         return ZK_ERR_NO_DEVICE;
     }
     return ZK_OK;
+}
+
+int &msm_chunk_log_override() {
+    static int v = 0;
+    return v;
+}
+
+// Plans own device memory, streams and (NTT) a per-device kernel attribute: they work on the device they were created on only.
+static int check_plan_device(int plan_device, const char *who) {
+    int cur = -1;
+    ZK_HIP(hipGetDevice(&cur));
+    if (cur == plan_device) return ZK_OK;
+    char buf[160];
+    snprintf(buf, sizeof(buf), "%s: the plan belongs to device %d but the calling thread's current device is %d", who, plan_device, cur);
+    return invalid(buf);
+}
+
+static bool fr_canonical_nonzero(const uint64_t v[4]) {
+    const HFr m = HFr::modulus();
+    if ((v[0] | v[1] | v[2] | v[3]) == 0) return false;
+    for (int k = 3; k >= 0; k--) {
+        if (v[k] < m.l[k]) return true;
+        if (v[k] > m.l[k]) return false;
+    }
+    return false;
 }
 
 static bool scalars_canonical(const uint64_t *s, size_t n) {
@@ -230,18 +256,26 @@ template <class F> static int msm_host(int group, const uint64_t *scalars, const
         return ZK_OK;
     }
     if (!scalars_canonical(scalars, n)) return invalid("zk_msm: scalar not canonical (>= r)");
-    static thread_local std::unique_ptr<MsmPlanBase> small_plan[3];
-    static thread_local std::unique_ptr<DevBuf> small_in[3];
+    // cached per (device, group): a plan's buffers and streams live on the device that was current when it was made
+    struct SmallCtx {
+        std::unique_ptr<MsmPlanBase> plan;
+        DevBuf in;
+    };
+    static thread_local std::map<std::pair<int, int>, std::unique_ptr<SmallCtx>> small;
     std::unique_ptr<MsmPlanBase> big_plan;
     MsmPlanBase *plan;
     DevBuf big_in, *in;
     if (n <= SMALL) {
-        if (!small_plan[group]) {
-            small_plan[group].reset(msm_plan_new(group, SMALL));
-            small_in[group].reset(new DevBuf(SMALL * (32 + PB)));
+        int dev = 0;
+        ZK_HIP(hipGetDevice(&dev));
+        std::unique_ptr<SmallCtx> &ctx = small[std::make_pair(dev, group)];
+        if (!ctx) {
+            ctx.reset(new SmallCtx);
+            ctx->plan.reset(msm_plan_new(group, SMALL));
+            ctx->in.alloc(SMALL * (32 + PB));
         }
-        plan = small_plan[group].get();
-        in = small_in[group].get();
+        plan = ctx->plan.get();
+        in = &ctx->in;
     } else {
         big_plan.reset(msm_plan_new(group, n));
         big_in.alloc(n * (32 + PB));
@@ -332,6 +366,11 @@ int zk_msm_plan_create(int group, size_t max_n, zk_msm_plan **plan) {
         return ZK_OK;
     });
 }
+int zk_test_set_msm_chunk_log(int log2_points) {
+    if (log2_points != 0 && (log2_points < 12 || log2_points > 24)) return invalid("zk_test_set_msm_chunk_log: 0 (default) or 12..24");
+    msm_chunk_log_override() = log2_points;
+    return ZK_OK;
+}
 int zk_msm_plan_destroy(zk_msm_plan *plan) {
     delete plan;
     return ZK_OK;
@@ -350,6 +389,7 @@ int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n) { return plan ? p
 int zk_msm_plan_bind_points(zk_msm_plan *plan, const void *d_points, size_t n, void *stream) {
     return guarded([&] {
         if (!plan || (n && !d_points)) return invalid("zk_msm_plan_bind_points: null pointer");
+        if (int rc = check_plan_device(plan->impl->device, "zk_msm_plan_bind_points")) return rc;
         return plan->impl->bind_points(d_points, n, (hipStream_t)stream);
     });
 }
@@ -357,18 +397,21 @@ int zk_msm_plan_max_in_flight(const zk_msm_plan *plan) { return plan ? plan->imp
 int zk_msm_dev(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xy, int *out_is_inf, void *stream) {
     return guarded([&] {
         if (!plan || !out_xy || (n && !d_scalars)) return invalid("zk_msm_dev: null pointer");
+        if (int rc = check_plan_device(plan->impl->device, "zk_msm_dev")) return rc;
         return plan->impl->run_affine(d_scalars, d_points, n, out_xy, out_is_inf, (hipStream_t)stream);
     });
 }
 int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, uint64_t *out_xyzz, void *stream) {
     return guarded([&] {
         if (!plan || !out_xyzz || (n && !d_scalars)) return invalid("zk_msm_dev_partial: null pointer");
+        if (int rc = check_plan_device(plan->impl->device, "zk_msm_dev_partial")) return rc;
         return plan->impl->run_partial(d_scalars, d_points, n, out_xyzz, (hipStream_t)stream);
     });
 }
 int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points, size_t n, void *stream, int *out_ticket) {
     return guarded([&] {
         if (!plan || !out_ticket || (n && !d_scalars)) return invalid("zk_msm_submit: null pointer");
+        if (int rc = check_plan_device(plan->impl->device, "zk_msm_submit")) return rc;
         *out_ticket = plan->impl->submit(d_scalars, d_points, n, (hipStream_t)stream);
         return ZK_OK;
     });
@@ -376,6 +419,7 @@ int zk_msm_submit(zk_msm_plan *plan, const void *d_scalars, const void *d_points
 int zk_msm_submit_bound(zk_msm_plan *plan, const void *d_scalars, size_t first, size_t n, void *stream, int *out_ticket) {
     return guarded([&] {
         if (!plan || !out_ticket || (n && !d_scalars)) return invalid("zk_msm_submit_bound: null pointer");
+        if (int rc = check_plan_device(plan->impl->device, "zk_msm_submit_bound")) return rc;
         *out_ticket = plan->impl->submit_bound(d_scalars, first, n, (hipStream_t)stream);
         return ZK_OK;
     });
@@ -469,6 +513,8 @@ int zk_ntt_plan_destroy(zk_ntt_plan *plan) {
 int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t coset_shift[4], void *stream) {
     return guarded([&] {
         if (!plan || !d_data) return invalid("zk_ntt_dev: null pointer");
+        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev")) return rc;
+        if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_dev: coset_shift must be a canonical non-zero element of F_r");
         plan->impl->run(d_data, inverse != 0, coset_shift, (hipStream_t)stream);
         return ZK_OK;
     });
@@ -476,6 +522,7 @@ int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t cose
 int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream) {
     return guarded([&] {
         if (!plan || (batch && !d_data)) return invalid("zk_ntt_dev_batch: null pointer");
+        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev_batch")) return rc;
         plan->impl->run(d_data, inverse != 0, nullptr, (hipStream_t)stream, batch);
         return ZK_OK;
     });
@@ -494,6 +541,7 @@ int zk_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t coset_
         if (rc) return rc;
         const size_t n = (size_t)1 << log_n;
         if (!scalars_canonical(data, n)) return invalid("zk_ntt_fr: element not canonical (>= r)");
+        if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_fr: coset_shift must be a canonical non-zero element of F_r");
         NttPlan plan(log_n);
         DevBuf d(n * 32);
         ZK_HIP(hipMemcpy(d.p, data, n * 32, hipMemcpyHostToDevice));
@@ -573,6 +621,7 @@ int zk_fr_scan_dev(zk_frvec *ws, void *d_data, size_t n, int op, int reverse, vo
 int zk_fr_quotient_dev(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, void *stream) {
     return guarded([&] {
         if (!d_out || !d_a || !d_b || !d_c || !zinv) return invalid("zk_fr_quotient_dev: null pointer");
+        if (!scalars_canonical(zinv, 1)) return invalid("zk_fr_quotient_dev: zinv not canonical (>= r)");
         fr_quotient(d_out, d_a, d_b, d_c, zinv, n, (hipStream_t)stream);
         return ZK_OK;
     });

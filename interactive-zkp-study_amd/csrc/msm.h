@@ -9,6 +9,7 @@ namespace zk {
 
 struct MsmPlanBase {
     int group = 0;
+    int device = 0;                        // the device the workspace lives on (set at creation; calls from another current device are refused)
     bool profile = false;                  // record HIP events around the pipeline stages
     float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};  // last run: prepare, bucket sort, accumulate, reduce (device ms)
     virtual ~MsmPlanBase() {}
@@ -24,6 +25,9 @@ struct MsmPlanBase {
     virtual int bind_points(const void *d_points, size_t n, hipStream_t st) = 0;
     virtual int submit_bound(const void *d_scalars, size_t first, size_t n, hipStream_t st) = 0;
 };
+// Test hook (zk_test_set_msm_chunk_log): log2 of the chunk size MSM plans created from now on use; 0 = the default 2^22.
+int &msm_chunk_log_override();
+
 // all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use
 MsmPlanBase *msm_plan_new_g1(size_t max_n, bool all_lanes);
 MsmPlanBase *msm_plan_new_g2(size_t max_n, bool all_lanes);

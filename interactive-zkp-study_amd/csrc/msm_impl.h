@@ -140,6 +140,10 @@ struct SortBufs {
     uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
     uint2 *heavy_tasks;     // [heavy_cap] (bucket id, segment index)
     uint4 *heavy_buckets;   // [heavy_cap] (bucket id, first task, segments, -)
+    // Device-side error counter of the lane (never reset: the host compares it with the value it saw last).  Bumped when an
+    // input breaks a precondition the host cannot check on device buffers (a scalar >= 2^255: the signed-digit carry leaves
+    // the top window) or when a heavy bucket does not fit the task arrays; the submission then fails at collect.
+    uint32_t *err;
 };
 __device__ __forceinline__ uint32_t size_bin(uint32_t c, uint32_t heavy_th) {
     return c > heavy_th ? 0u : min(c, (uint32_t)SIZE_BINS - 1u);
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(PREP_NT) void msm_prepare_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ points,
                                                               PackedAffine<F> *__restrict__ pts_m,
                                                               int16_t *__restrict__ digits, uint32_t *__restrict__ cell_total,
-                                                              uint32_t n, uint32_t n_pad) {
+                                                              uint32_t *__restrict__ err, uint32_t n, uint32_t n_pad) {
     constexpr int W = (255 + C - 1) / C;
     constexpr int PW = F::CANON_WORDS;
     constexpr int G = ((1 << (C - 1)) + SEG_BUCKETS - 1) / SEG_BUCKETS;
@@ -215,6 +219,9 @@ __global__ __launch_bounds__(PREP_NT) void msm_prepare_kernel(const uint32_t *__
             digits[(size_t)w * n_pad + i] = (int16_t)d;
             if (d != 0) atomicAdd(&hist[w * G + (((uint32_t)(d < 0 ? -d : d) - 1u) >> SEG_LOG)], 1u);
         }
+        // a canonical scalar (< r < 2^254, or k + r < 2^255 above) never carries out of the top window; one that does
+        // (>= 2^255 for c = 15, 16) would silently lose 2^(W*C) * P
+        if ((carry || (W * C < 256 && (s[7] >> (W * C - 224)) != 0)) && !inf) atomicAdd(err, 1u);
     }
     __syncthreads();
     for (uint32_t k = t; k < W * G; k += PREP_NT) {
@@ -466,8 +473,9 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbu
                 const uint32_t nseg = (cc[q] + HEAVY_WAVE - 1) / HEAVY_WAVE;  // wavefront tasks of 64 segments
                 const uint32_t tpos = atomicAdd(&B.heavy_ctr[0], nseg);
                 const uint32_t hb = atomicAdd(&B.heavy_ctr[1], 1u);
-                // capacity is sized so this always holds; an unregistered bucket would be caught by the closed-form tests
+                // capacity is sized so this always holds; if it ever does not, the submission fails at collect
                 if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) B.heavy_buckets[hb] = make_uint4(b0i + q, tpos, nseg, 0u);
+                else atomicAdd(B.err, 1u);
             }
         }
     }
@@ -743,6 +751,19 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // stage boundaries when profiling; [5], [6] bracket the accumulate kernel
         bool ready = false, busy = false, empty = false, profiled = false, single_window = false;
         int c = 0;
+        uint32_t err_seen = 0;  // value of the lane's device error counter at the last collect
+    };
+    // The read-back buffer of a lane: a 16-byte header (word 0 = the lane's device error counter, see SortBufs::err) followed by
+    // the window / level sums, so that one copy brings both back.
+    static constexpr size_t OUT_HDR = 16;
+    static uint32_t *err_dev(Lane &L) { return L.out.template as<uint32_t>(); }
+    static Xyzz<F> *out_dev(Lane &L) { return reinterpret_cast<Xyzz<F> *>(static_cast<char *>(L.out.p) + OUT_HDR); }
+    static const Xyzz<F> *out_host(const Lane &L) { return reinterpret_cast<const Xyzz<F> *>(static_cast<const char *>(L.h_out.p) + OUT_HDR); }
+    struct LaneGuard {
+        Lane *lane;
+        ~LaneGuard() {
+            if (lane) lane->busy = false;
+        }
     };
     static constexpr int MAX_LANES = 3;
     Lane lanes[MAX_LANES];
@@ -755,9 +776,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // host): the packed bases of a chunk (256 MB) stay within reach of the Infinity Cache and the TLB -- at 2^26 in one
     // piece the gathers of the accumulate kernel run 40 % slower -- and the chunks overlap like any other submissions
     // (2^24: 26.3 -> 24.0 ms, 2^26: 138 -> 93 ms).  The workspace never exceeds that of a 2^22-point MSM.
-    static size_t chunk_points() {  // ZK_MSM_CHUNK_LOG: test knob (chunking at sizes the oracle can check)
-        const char *e = getenv("ZK_MSM_CHUNK_LOG");
-        const int l = e ? atoi(e) : 22;
+    static size_t chunk_points() {  // 2^22 unless a test moved it (zk_test_set_msm_chunk_log: chunking at sizes the oracle can check)
+        const int l = msm_chunk_log_override() ? msm_chunk_log_override() : 22;
         return (size_t)1 << (l < 12 ? 12 : l > 24 ? 24 : l);
     }
     static constexpr int BIG_TICKET = 64;
@@ -771,6 +791,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
 
     explicit MsmPlanImpl(size_t max_n_, bool all_lanes = false) : max_n(max_n_) {
         group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
+        ZK_HIP(hipGetDevice(&device));
         cap_n = std::min(max_n, chunk_points());
         const size_t n_pad = pad_n(cap_n);
         // worst case over the window choices available to n <= max_n
@@ -818,8 +839,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.heavy_partial.alloc((size_t)heavy_cap * sizeof(Xyzz<F>));
         L.perm.alloc(nbk * sizeof(uint32_t));
         L.arena.alloc(arena_bytes);
-        L.out.alloc(out_bytes_max);
-        L.h_out.alloc(out_bytes_max);
+        L.out.alloc(out_bytes_max + OUT_HDR);
+        ZK_HIP(hipMemset(L.out.p, 0, OUT_HDR));
+        L.h_out.alloc(out_bytes_max + OUT_HDR);
         ZK_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         L.ready = true;
@@ -847,7 +869,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
 
     template <int C> void launch_prepare(Lane &L, const uint32_t *sc, const uint32_t *pt, uint32_t n, uint32_t n_pad) {
         hipLaunchKernelGGL((msm_prepare_kernel<F, C>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, L.stream, sc, pt,
-                           L.pts_m.template as<PackedAffine<F>>(), L.digits.template as<int16_t>(), L.cells.template as<uint32_t>(), n, n_pad);
+                           L.pts_m.template as<PackedAffine<F>>(), L.digits.template as<int16_t>(), L.cells.template as<uint32_t>(), err_dev(L), n, n_pad);
     }
     SortBufs sort_bufs(Lane &L) {
         SortBufs B;
@@ -870,6 +892,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
         B.heavy_tasks = L.heavy_tasks.template as<uint2>();
         B.heavy_buckets = L.heavy_buckets.template as<uint4>();
+        B.err = err_dev(L);
         return B;
     }
     void launch_sort_accumulate(Lane &L, uint32_t n_pad, uint32_t nb, uint32_t W) {
@@ -955,6 +978,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.single_window = true;
         L.c = FIX_C;
         next_lane = (next_lane + 1) % nlanes;
+        LaneGuard guard{&L};   // a launch that throws must not leave the lane marked busy
         hipStream_t ls = L.stream;
         ZK_HIP(hipEventRecord(L.ev_in, st));
         ZK_HIP(hipStreamWaitEvent(ls, L.ev_in, 0));
@@ -993,14 +1017,15 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         for (uint32_t step = 0; step < levels - BL; step++) {
             const uint32_t ntasks = (step + 1 + BL) << (levels - BL - 1 - step);
             hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3((ntasks + 255) / 256, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(),
-                               L.out.template as<Xyzz<F>>(), FIX_NB, BL, levels, step, 0u);
+                               out_dev(L), FIX_NB, BL, levels, step, 0u);
         }
-        hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3(1, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(), L.out.template as<Xyzz<F>>(),
+        hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3(1, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(), out_dev(L),
                            FIX_NB, BL, levels, 0u, 1u);
         mark(L, 4);
-        ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, (size_t)(levels + 1) * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, ls));
+        ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, OUT_HDR + (size_t)(levels + 1) * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, ls));
         ZK_HIP(hipEventRecord(L.done, ls));
         ZK_HIP(hipGetLastError());
+        guard.lane = nullptr;
         return ticket;
     }
     // n > CHUNK: every chunk is an ordinary submission; when the lanes run out the oldest chunk is collected (this call
@@ -1012,16 +1037,33 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         big.acc = Xyzz<HF>::inf();
         big.npend = 0;
         const uint32_t *sc = static_cast<const uint32_t *>(d_scalars), *pt = static_cast<const uint32_t *>(d_points);
-        for (size_t off = 0; off < n; off += cap_n) {
-            const size_t m = std::min(cap_n, n - off);
-            if (big.npend == nlanes) {
-                xyzz_add(big.acc, collect_lane(big.pend[0]));
-                for (int i = 1; i < big.npend; i++) big.pend[i - 1] = big.pend[i];
-                big.npend--;
+        try {
+            for (size_t off = 0; off < n; off += cap_n) {
+                const size_t m = std::min(cap_n, n - off);
+                if (big.npend == nlanes) {
+                    const int oldest = big.pend[0];
+                    for (int i = 1; i < big.npend; i++) big.pend[i - 1] = big.pend[i];
+                    big.npend--;
+                    xyzz_add(big.acc, collect_lane(oldest));
+                }
+                big.pend[big.npend++] = d_points ? submit_lane(sc + off * 8, pt + off * 2 * F::CANON_WORDS, m, st) : submit_lane_fixed(sc + off * 8, first + off, m, st);
             }
-            big.pend[big.npend++] = d_points ? submit_lane(sc + off * 8, pt + off * 2 * F::CANON_WORDS, m, st) : submit_lane_fixed(sc + off * 8, first + off, m, st);
+        } catch (...) {
+            abandon_big();
+            throw;
         }
         return BIG_TICKET;
+    }
+    // A chunk failed: wait for the chunks still in flight, free their lanes and forget the submission, so the plan stays usable.
+    void abandon_big() {
+        for (int i = 0; i < big.npend; i++) {
+            try {
+                (void)collect_lane(big.pend[i]);
+            } catch (...) {
+            }
+        }
+        big.npend = 0;
+        big.active = false;
     }
     int submit_lane(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
         const int ticket = next_lane;
@@ -1034,6 +1076,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.single_window = false;
         next_lane = (next_lane + 1) % nlanes;
         if (n == 0) return ticket;
+        LaneGuard guard{&L};
         const int c = pick_window_bits(n);
         L.c = c;
         const uint32_t W = (255 + c - 1) / c, nb = 1u << (c - 1), levels = c - 1;
@@ -1057,22 +1100,32 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             const uint32_t BL = std::min<uint32_t>(9, levels);
             const uint32_t threads = std::max<uint32_t>(64, 1u << (BL - 1));
             hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3((W * nb) >> BL), dim3(threads), 0, L.stream, ar, BL);
-            hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, L.stream, ar, L.out.template as<Xyzz<F>>(), nb, BL, levels);
+            hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, L.stream, ar, out_dev(L), nb, BL, levels);
         }
         mark(L, 4);
-        const size_t out_bytes = (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
+        const size_t out_bytes = OUT_HDR + (size_t)W * (levels + 1) * sizeof(Xyzz<F>);
         ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, out_bytes, hipMemcpyDeviceToHost, L.stream));
         ZK_HIP(hipEventRecord(L.done, L.stream));
         ZK_HIP(hipGetLastError());
+        guard.lane = nullptr;
         return ticket;
     }
 
     // Waits for a submission and folds its window/level sums on the host.
     Xyzz<HF> collect(int ticket) {
         if (ticket == BIG_TICKET && big.active) {
-            for (int i = 0; i < big.npend; i++) xyzz_add(big.acc, collect_lane(big.pend[i]));
+            try {
+                while (big.npend) {
+                    const int oldest = big.pend[0];
+                    for (int i = 1; i < big.npend; i++) big.pend[i - 1] = big.pend[i];
+                    big.npend--;
+                    xyzz_add(big.acc, collect_lane(oldest));
+                }
+            } catch (...) {
+                abandon_big();
+                throw;
+            }
             big.active = false;
-            big.npend = 0;
             return big.acc;
         }
         return collect_lane(ticket);
@@ -1089,10 +1142,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             ZK_HIP(hipEventElapsedTime(&stage_ms[2], L.ev[5], L.ev[6]));  // the accumulate kernel alone
             ZK_HIP(hipEventElapsedTime(&stage_ms[3], L.ev[3], L.ev[4]));
         }
+        const uint32_t err_now = *L.h_out.template as<uint32_t>();
+        if (err_now != L.err_seen) {
+            L.err_seen = err_now;
+            throw std::runtime_error("zk_msm: invalid input detected on the device (a non-canonical scalar near or above 2^255 whose signed digits "
+                                     "do not fit the windows, or a heavy bucket beyond the plan's task capacity); no result");
+        }
         const int c = L.c;
         const uint32_t W = L.single_window ? 1u : (uint32_t)((255 + c - 1) / c), levels = c - 1;
         // Host fold: result = sum_w 2^(c w) * (T_w + sum_l 2^l O_{w,l}); one Horner pass over bit positions.
-        const Xyzz<F> *h = L.h_out.template as<Xyzz<F>>();
+        const Xyzz<F> *h = out_host(L);
         auto conv = [](const Xyzz<F> &p) { return Xyzz<HF>{HF::from_dev(p.x), HF::from_dev(p.y), HF::from_dev(p.zz), HF::from_dev(p.zzz)}; };
         Xyzz<HF> acc = Xyzz<HF>::inf();
         for (int pos = (int)(c * (W - 1) + levels - 1); pos >= 0; pos--) {

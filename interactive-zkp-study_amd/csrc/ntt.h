@@ -33,11 +33,13 @@ class NttPlan {
     // four-step transform of n = 2^log_n points whose second dimension has 2^log_cols points.
     void twiddle_2d(void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, bool inverse, hipStream_t st);
     unsigned log_n() const { return L_; }
+    int device() const { return device_; }
 
   private:
     void build_tables();
     void coset_tables(const uint64_t k[4], bool inverse);
     unsigned L_;
+    int device_ = 0;  // the device the tables live on; run() refuses any other current device
     std::vector<uint32_t> digits_;  // log2 of each pass's digit, pass 1 first
     uint32_t lmax_ = 0, lh_ = 0;
     DevBuf tmp_;

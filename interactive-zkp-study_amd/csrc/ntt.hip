@@ -290,7 +290,10 @@ NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     lh_ = (L_ + 1) / 2;
     build_tables();
     // the inter-pass scratch (n * 36 bytes per transform in flight) is allocated by the first run()
-    static bool attr_done = false;
+    // per device: the opt-in to more than 64 KiB of dynamic LDS belongs to the function ON the current device
+    static bool attr_done_dev[64] = {};
+    ZK_HIP(hipGetDevice(&device_));
+    bool &attr_done = attr_done_dev[device_ & 63];
     if (!attr_done) {
         const void *fns[4] = {reinterpret_cast<const void *>(&ntt_pass_kernel<false, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<false, false>),
                               reinterpret_cast<const void *>(&ntt_pass_kernel<true, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<true, false>)};

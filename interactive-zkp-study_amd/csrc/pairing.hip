@@ -274,11 +274,45 @@ G2Aff load_g2(const uint64_t *p) {
     return a;
 }
 
+// Input validation, as py_ecc's pairing() does before anything else (bn128_pairing.py: `assert is_on_curve(Q, b2)`,
+// `assert is_on_curve(P, b)`; infinity passes): coordinates must be canonical (< p) and the point must satisfy its curve
+// equation -- y^2 = x^3 + 3 on G1, y^2 = x^3 + 3/(9 + i) on the twist.  An off-curve "point" would otherwise run through the
+// Miller loop and give a meaningless value, so a verifier would accept or reject on garbage.  Like the reference, this does
+// NOT test that a twist point lies in the order-r subgroup (G1 has cofactor 1, so on-curve is enough there).
+bool fp_words_canonical(const uint64_t *w) {
+    const HFp m = HFp::modulus();
+    for (int k = 3; k >= 0; k--) {
+        if (w[k] < m.l[k]) return true;
+        if (w[k] > m.l[k]) return false;
+    }
+    return false;
+}
+bool g1_input_ok(const uint64_t *p) {
+    if (!fp_words_canonical(p) || !fp_words_canonical(p + 4)) return false;
+    const G1Aff a = load_g1(p);
+    if (a.inf) return true;
+    const HFp rhs = fe_add(fe_mul(fe_sqr(a.x), a.x), hfe_from_u64<FpTag>(3));
+    return fe_sqr(a.y).equals(rhs);
+}
+bool g2_input_ok(const uint64_t *p) {
+    for (int k = 0; k < 4; k++)
+        if (!fp_words_canonical(p + 4 * k)) return false;
+    const G2Aff a = load_g2(p);
+    if (a.inf) return true;
+    static const HFp2 b2 = fp2_mul_fp(fe_inv(HFp2{hfe_from_u64<FpTag>(9), HFp::one()}), hfe_from_u64<FpTag>(3));  // 3 / (9 + i)
+    const HFp2 rhs = fe_add(fe_mul(fe_sqr(a.x), a.x), b2);
+    return fe_sqr(a.y).equals(rhs);
+}
+
 }  // namespace
 
 // prod_i e(P_i, Q_i) with ONE final exponentiation; out (nullable): 12 canonical F_p coefficients
 // in py_ecc's F_p[w]/(w^12 - 18 w^6 + 82) basis; *is_one: whether the product is the identity.
 int pairing_product(const uint64_t *g1_points, const uint64_t *g2_points, size_t n, uint64_t *out, int *is_one) {
+    for (size_t i = 0; i < n; i++) {
+        if (!g1_input_ok(g1_points + 8 * i)) return invalid("zk_pairing: a G1 input is not a canonical point of y^2 = x^3 + 3");
+        if (!g2_input_ok(g2_points + 16 * i)) return invalid("zk_pairing: a G2 input is not a canonical point of the twist y^2 = x^3 + 3/(9+i)");
+    }
     Fp12 f = Fp12::one();
     for (size_t i = 0; i < n; i++) f = f12_mul(f, miller_loop(load_g2(g2_points + 16 * i), load_g1(g1_points + 8 * i)));
     f = final_exp(f);

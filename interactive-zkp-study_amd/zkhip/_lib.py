@@ -72,6 +72,7 @@ _PROTOS = {
     "zk_fixed_base_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_group_op": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, _VP, _SZ, _VP]),
     "zk_measure_rate": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "zk_test_set_msm_chunk_log": (ctypes.c_int, [ctypes.c_int]),
     "zk_pairing": (ctypes.c_int, [_VP, _VP, _VP]),
     "zk_pairing_check": (ctypes.c_int, [_VP, _VP, _SZ, ctypes.POINTER(ctypes.c_int)]),
 }

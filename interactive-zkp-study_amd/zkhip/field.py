@@ -349,8 +349,16 @@ def ec_pairing(g2_point, g1_point):
     P = g1_to_limbs([g1_point])
     Q = g2_to_limbs([g2_point])
     out = np.zeros(48, dtype=np.uint64)
-    _lib.check(_lib.load().zk_pairing(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(out)))
+    _check_pairing_inputs(_lib.load().zk_pairing(_lib.ptr(P), _lib.ptr(Q), _lib.ptr(out)))
     return FQ12(_lib.limbs_to_ints(out))
+
+
+def _check_pairing_inputs(rc):
+    """py_ecc's pairing asserts is_on_curve for both arguments (bn128_pairing.py); libzkhip reports the same condition as
+    ZK_ERR_INVALID, raised here as the reference's AssertionError so that callers see one behaviour."""
+    if rc == _lib.ZK_ERR_INVALID:
+        raise AssertionError(_lib.load().zk_last_error().decode("utf-8", "replace"))
+    _lib.check(rc)
 
 
 def pairing_check(pairs):
@@ -360,7 +368,7 @@ def pairing_check(pairs):
     P = g1_to_limbs([p for p, _ in pairs])
     Q = g2_to_limbs([q for _, q in pairs])
     ok = _lib.ctypes.c_int(0)
-    _lib.check(_lib.load().zk_pairing_check(_lib.ptr(P), _lib.ptr(Q), len(pairs), _lib.ctypes.byref(ok)))
+    _check_pairing_inputs(_lib.load().zk_pairing_check(_lib.ptr(P), _lib.ptr(Q), len(pairs), _lib.ctypes.byref(ok)))
     return bool(ok.value)
 
 

@@ -189,7 +189,12 @@ class ScaleProver:
         coefficient vector u_C); d_w: device (W, 4) witness.
         -> (proof_A, proof_B, proof_C) as points, plus the device buffer of the H coefficients."""
         import torch
-        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        if stream is not None and stream != torch.cuda.current_stream().cuda_stream:
+            # the copies below are torch calls (current stream), the transforms and MSMs go to `stream`: run the whole proof with
+            # `stream` as torch's current stream so that both are ordered on it
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                return self.prove(d_a, d_b, d_c, d_w, r, s, None)
+        st = torch.cuda.current_stream().cuda_stream
         m, W, crs = self.m, self.W, self.crs
         r, s = r % R, s % R
         ca, cb, cc, h = self.scratch
@@ -283,7 +288,10 @@ class ShardedScaleProver(ScaleProver):
     def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
         import torch
         from ..distributed import all_gather_partials, fold_partials
-        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        if stream is not None and stream != torch.cuda.current_stream().cuda_stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):                # see ScaleProver.prove
+                return self.prove(d_a, d_b, d_c, d_w, r, s, None)
+        st = torch.cuda.current_stream().cuda_stream
         m, W, crs = self.m, self.W, self.crs
         r, s = r % R, s % R
         ca, cb, cc, h = self.scratch

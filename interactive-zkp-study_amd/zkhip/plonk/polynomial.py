@@ -65,6 +65,11 @@ class Polynomial:
             other = Polynomial([other])
         return self + (-other)
 
+    def __rsub__(self, other):
+        if isinstance(other, (int, FR)):
+            other = Polynomial([other])
+        return other.__sub__(self)
+
     def __mul__(self, other):
         if isinstance(other, (int, FR)):
             s = FR(other)
@@ -80,9 +85,40 @@ class Polynomial:
     __rmul__ = __mul__
 
     def __eq__(self, other):
+        if isinstance(other, (int, FR)):
+            other = Polynomial([other])
         if not isinstance(other, Polynomial):
-            return NotImplemented
+            return False
         return self.coeffs == other.coeffs
+
+    __hash__ = None
+
+    def __len__(self):
+        return len(self.coeffs)
+
+    def scale(self, scalar):
+        """scalar * p(x) (polynomial.py:189-198)."""
+        return self * scalar
+
+    def divide_by_vanishing(self, n):
+        """p(x) / (x^n - 1); ValueError unless the division is exact (polynomial.py:200-224)."""
+        q, r = poly_div(self, Polynomial.vanishing(n))
+        if not r.is_zero():
+            raise ValueError("not divisible by the vanishing polynomial (constraints unsatisfied)")
+        return q
+
+    @staticmethod
+    def _vanishing_coeffs(n):
+        return Polynomial([FR(CURVE_ORDER - 1)] + [FR(0)] * (n - 1) + [FR(1)])
+
+    @classmethod
+    def one(cls):
+        return cls([FR(1)])
+
+    @classmethod
+    def vanishing(cls, n):
+        """Z_H(x) = x^n - 1 (polynomial.py:243-261)."""
+        return cls._vanishing_coeffs(n)
 
     def __repr__(self):
         return "Polynomial(%r)" % ([c.n for c in self.coeffs],)
@@ -176,3 +212,16 @@ def poly_div(a, b):
             for j in range(deg_b + 1):
                 rem[i + j] = (rem[i + j] - coeff * div[j]) % CURVE_ORDER
     return Polynomial(quot), Polynomial(rem)
+
+
+def lagrange_basis(domain, i):
+    """L_i(x) = prod_{j != i} (x - d_j) / (d_i - d_j) in coefficient form (polynomial.py:438-475); scalar host glue
+    (the reference's round 3 uses it for L_1; the backend's round 3 evaluates L_1 in closed form on the coset)."""
+    result = Polynomial([FR(1)])
+    denominator = FR(1)
+    for j, dj in enumerate(domain):
+        if j == i:
+            continue
+        result = result * Polynomial([FR(0) - dj, FR(1)])
+        denominator = denominator * (domain[i] - dj)
+    return result * (FR(1) / denominator)

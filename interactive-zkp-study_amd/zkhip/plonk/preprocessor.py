@@ -6,13 +6,7 @@ from .circuit import Gate
 from .kzg import commit
 from .permutation import build_permutation_polynomials
 from .polynomial import Polynomial
-
-
-def next_power_of_2(n):
-    p = 1
-    while p < n:
-        p <<= 1
-    return p
+from .utils import next_power_of_2
 
 
 class PreprocessedData:

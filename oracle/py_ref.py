@@ -698,7 +698,11 @@ def miller_loop(Q, Pt):
 
 
 def pairing(Q, Pt):
-    """py_ecc.bn128.pairing(Q in G2, P in G1) -> F_p^12 coefficient list (12 ints)."""
+    """py_ecc.bn128.pairing(Q in G2, P in G1) -> F_p^12 coefficient list (12 ints).  Like py_ecc's, it asserts that
+    both arguments lie on their curves (bn128_pairing.pairing: `assert is_on_curve(Q, b2)`, `assert is_on_curve(P, b)`;
+    infinity passes)."""
+    assert g2_is_on_curve(Q), "pairing: Q is not on the twist"
+    assert g1_is_on_curve(Pt), "pairing: P is not on the curve"
     return miller_loop(twist(Q), cast_g1_to_f12(Pt))
 
 

@@ -19,6 +19,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
 import py_ref as o  # noqa: E402
+import plonk_ref as pl  # noqa: E402
 
 
 def s(v):
@@ -107,7 +108,68 @@ def ntt():
     })
 
 
+PLONK_CASES = {
+    # the reference's fixture: Circuit.x3_plus_x_plus_5_eq_35(), SRS.generate(20, seed=42) (tests/plonk/test_prover.py:43-60,
+    # tests/plonk/test_e2e.py:52-66); blinding scalars are what secrets.randbelow would have drawn, fixed here
+    "toy_x3": {"make": pl.circuit_x3_plus_x_plus_5_eq_35, "srs_degree": 20, "seed": 42,
+               "blinding": [pow(7, 50 + k, o.R) for k in range(9)]},
+    # a second circuit: six gates padded to n = 8, blinding with a zero top coefficient (Polynomial._trim shortens the blinder)
+    "six_gates_n8": {"make": pl.circuit_six_gates, "srs_degree": 40, "seed": 42,
+                     "blinding": [pow(11, 90 + k, o.R) for k in range(8)] + [0]},
+}
+
+
+def plonk():
+    out = {"source": "zkp/plonk/prover/round1..5.py, verifier.py, preprocessor.py restated in oracle/plonk_ref.py (O(n^2) products, poly_div, "
+                     "Horner); circuit / SRS fixtures: tests/plonk/test_prover.py:43-60; the nine blinding scalars are injected in draw order "
+                     "(a a b b c c z z z)", "cases": {}}
+    for name, spec in PLONK_CASES.items():
+        srs = o.srs_generate(spec["srs_degree"], spec["seed"])
+        circuit, a, b, c, pub = spec["make"]()
+        gates_in = [list(g) for g in circuit.gates]
+        pp = pl.preprocess(circuit, srs)
+        assert pl.gates_satisfied(circuit, a, b, c)
+        proof, st = pl.prove(circuit, a, b, c, pub, pp, srs, spec["blinding"], return_state=True)
+        assert st.rem_zeta == [0] and st.rem_zeta_omega == [0]
+        assert pl.verify(proof, pub, pp, srs)
+        # second method for every field: commitments are p(tau) * G1, evaluations are Horner values of the stored polynomials,
+        # the quotient satisfies C = t * Z_H at an independent point
+        tau = o.srs_tau(spec["seed"])
+        for fld, poly in (("a_comm", st.a_poly), ("b_comm", st.b_poly), ("c_comm", st.c_poly), ("z_comm", st.z_poly),
+                          ("t_lo_comm", st.t_lo_poly), ("t_mid_comm", st.t_mid_poly), ("t_hi_comm", st.t_hi_poly)):
+            assert getattr(proof, fld) == o.g1_multiply(o.G1, o.horner(poly, tau)), fld
+        n, w = pp.n, pp.omega
+        x = 0x1234567
+        ev = lambda poly, at=x: o.horner(poly, at)
+        zh = (pow(x, n, o.R) - 1) % o.R
+        t_x = (ev(st.t_lo_poly) + pow(x, n, o.R) * ev(st.t_mid_poly) + pow(x, 2 * n, o.R) * ev(st.t_hi_poly)) % o.R
+        aa, bb, cc, zz, zw = ev(st.a_poly), ev(st.b_poly), ev(st.c_poly), ev(st.z_poly), ev(st.z_poly, x * w % o.R)
+        gate = (ev(pp.q_l_poly) * aa + ev(pp.q_r_poly) * bb + ev(pp.q_o_poly) * cc + ev(pp.q_m_poly) * aa * bb + ev(pp.q_c_poly)) % o.R
+        num = (aa + st.beta * x + st.gamma) * (bb + st.beta * 2 * x + st.gamma) * (cc + st.beta * 3 * x + st.gamma) * zz % o.R
+        den = ((aa + st.beta * ev(pp.s_sigma1_poly) + st.gamma) * (bb + st.beta * ev(pp.s_sigma2_poly) + st.gamma)
+               * (cc + st.beta * ev(pp.s_sigma3_poly) + st.gamma) * zw) % o.R
+        l1 = pl.lagrange_basis_eval(0, n, w, x)
+        assert (gate + st.alpha * (num - den) + st.alpha * st.alpha * (zz - 1) * l1 - t_x * zh) % o.R == 0
+        assert proof.r_eval == o.horner(st.r_poly, st.zeta)
+        assert st.t_eval * pl.vanishing_poly_eval(n, st.zeta) % o.R == proof.r_eval     # the verifier's t(zeta) = r(zeta) / Z_H(zeta)
+        out["cases"][name] = {
+            "srs": {"max_degree": spec["srs_degree"], "seed": spec["seed"]},
+            "gates": [[s(v) for v in g] for g in gates_in], "copy_constraints": [list(cc_) for cc_ in circuit.copy_constraints],
+            "n": pp.n, "a_vals": [s(v) for v in a], "b_vals": [s(v) for v in b], "c_vals": [s(v) for v in c],
+            "public_inputs": [s(v) for v in pub], "blinding": [s(v) for v in spec["blinding"]],
+            "sigma": pp.sigma,
+            "preprocessed": {k: g1(getattr(pp, k)) for k in ("q_l_comm", "q_r_comm", "q_o_comm", "q_m_comm", "q_c_comm",
+                                                             "s_sigma1_comm", "s_sigma2_comm", "s_sigma3_comm")},
+            "challenges": {k: s(getattr(st, k)) for k in ("beta", "gamma", "alpha", "zeta", "v")},
+            "polys": {k: [s(v) for v in getattr(st, k)] for k in ("a_poly", "b_poly", "c_poly", "z_poly", "t_lo_poly", "t_mid_poly", "t_hi_poly",
+                                                                   "r_poly")},
+            "proof": {f: (g1(getattr(proof, f)) if f in pl.PROOF_POINTS else s(getattr(proof, f))) for f in pl.PROOF_FIELDS},
+        }
+    dump("plonk_proofs.json", out)
+
+
 if __name__ == "__main__":
     toy_groth16()
     kzg()
     ntt()
+    plonk()

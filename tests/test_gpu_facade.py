@@ -263,6 +263,26 @@ def test_groth16_verify_true_and_tampered(pipeline):
     assert verify(p["prf_A"], p["prf_B"], p["prf_C"], p["s11"], p["s13"], p["s21"], wrong_pub) is False
 
 
+def test_verifiers_refuse_off_curve_proof_points(pipeline, srs_small):
+    """py_ecc's pairing asserts is_on_curve for both arguments, so the reference's verifiers raise on a proof element that
+    is not a curve point; the backend refuses the same inputs (AssertionError from the facade, ZK_ERR_INVALID at the ABI)
+    instead of running them through the Miller loop."""
+    p = pipeline
+    rx_pub = build_rpub_enum(p["t"]["pub"], p["Rx"])
+    off_a = (p["prf_A"][0], p["prf_A"][1] + FQ(1))
+    off_c = (p["prf_C"][0] + FQ(1), p["prf_C"][1])
+    off_b = (p["prf_B"][0], FQ2((p["prf_B"][1].coeffs[0] + FQ(1), p["prf_B"][1].coeffs[1])))
+    for args in ((off_a, p["prf_B"], p["prf_C"]), (p["prf_A"], off_b, p["prf_C"]), (p["prf_A"], p["prf_B"], off_c)):
+        with pytest.raises(AssertionError):
+            verify(args[0], args[1], args[2], p["s11"], p["s13"], p["s21"], rx_pub)
+    with pytest.raises(AssertionError):
+        lhs(off_a, p["prf_B"])
+    poly = Polynomial([FR(1), FR(2), FR(3)])
+    C, pi = commit(poly, srs_small), create_witness(poly, FR(5), srs_small)
+    with pytest.raises(AssertionError):
+        verify_opening(C, (pi[0], pi[1] + FQ(1)), FR(5), poly.evaluate(FR(5)), srs_small)
+
+
 def test_pairing_wrapper_bilinear():
     e = ec_pairing(G2, G1)
     assert isinstance(e, FQ12) and e != FQ12.one()

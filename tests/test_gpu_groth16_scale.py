@@ -52,6 +52,31 @@ def test_scale_prover_closed_form(log_m):
         assert hc[:len(q)] == q
 
 
+def test_scale_prover_on_a_side_stream():
+    """prove(..., stream=s) with s different from torch's current stream: the torch copies inside the prover and the backend's
+    kernels must be ordered on s (they used to run on two streams).  The inputs are produced on s right before the call, so
+    a prover that read them from the default stream's point of view would see stale data."""
+    import torch
+    circ = ChainCircuit(12, seed=5)
+    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 200))
+    w, a, b, c = circ.witness()
+    prover = ScaleProver(crs)
+    prover.load_r1cs(circ.r1cs_csr())
+    A, B, C = closed_form_scalars(crs, w, 4106, 4565)
+    want = (ec_mul(G1, A), ec_mul(G2, B), ec_mul(G1, C))
+    side = torch.cuda.Stream()
+    staging = _dev(w)
+    d_w = torch.zeros_like(staging)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            d_w.zero_()
+            d_w.copy_(staging)                                  # the witness appears on the side stream only
+        got = prover.prove_from_witness(d_w, 4106, 4565, stream=side.cuda_stream)
+        assert got[:3] == want
+    torch.cuda.synchronize()
+
+
 def test_scale_prover_2pow20_constraints_closed_form():
     """BASELINE.json configs[3] at its full size: Groth16 prove() on a synthetic 2^20-constraint R1CS, witness resident in HBM
     -> (A, B, C), against the closed-form scalars of the known toxic waste; the CRS queries are bound to the MSM plans as

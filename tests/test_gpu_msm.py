@@ -8,7 +8,7 @@ import pytest
 
 import c_oracle as co
 import py_ref as o
-from helpers import limb_row, rand_fr_limbs, rand_g1_limbs, rand_g2_limbs
+from helpers import arithmetic_g1_points, limb_row, rand_fr_limbs, rand_g1_limbs, rand_g2_limbs
 from zkhip import _lib
 from zkhip.device import MsmPlan
 from zkhip.distributed import fold_partials
@@ -329,11 +329,19 @@ def test_fixed_base_batches_bit_exact(n):
     assert not out1.any()
 
 
-def test_chunked_msm_small_chunks(monkeypatch):
+@pytest.fixture
+def chunk_log():
+    """zk_test_set_msm_chunk_log for the plans a test creates; restored to the default afterwards."""
+    lib = _lib.load()
+    yield lambda l: _lib.check(lib.zk_test_set_msm_chunk_log(l))
+    _lib.check(lib.zk_test_set_msm_chunk_log(0))
+
+
+def test_chunked_msm_small_chunks(chunk_log):
     """MSMs beyond the chunk size (2^24 points; here 2^12 through the test knob) run as consecutive chunks in the
     plan's lanes with the partial sums added on the host: blocking, pipelined and partial forms, bit-exact."""
     import torch
-    monkeypatch.setenv("ZK_MSM_CHUNK_LOG", "12")
+    chunk_log(12)
     rng = np.random.default_rng(31)
     n = 5 * 4096 + 123
     S = rand_fr_limbs(rng, n)
@@ -412,12 +420,12 @@ def o_point(pt):
 
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
-def test_bound_bases_mode_equals_unbound(group, monkeypatch):
+def test_bound_bases_mode_equals_unbound(group, chunk_log):
     """zk_msm_plan_bind_points: the 13-row table of 2^(20 w) * P_i and one window of 2^19 buckets must give the very same
     points as the ordinary 16-window path -- uniform and skewed scalars, prefixes of the bound bases, infinity among the
     bases, three submissions in flight, and a chunked call (test knob) that walks the table with an offset."""
     import torch
-    monkeypatch.setenv("ZK_MSM_CHUNK_LOG", "18")                     # plan workspace for 2^18 points: chunking at testable sizes
+    chunk_log(18)                     # plan workspace for 2^18 points: chunking at testable sizes
     rng = np.random.default_rng(41)
     g2 = group == "g2"
     n = (1 << 18) + 5000 if not g2 else 9000
@@ -497,3 +505,94 @@ def test_g1_top_window_spreading_edges():
     m = 3000
     assert ints(plan.run(dS.data_ptr(), dP.data_ptr(), m, st)) == ints(co.g1_mul(o.G1, arithmetic_dot(S[:m], k0, d)))
     plan.close()
+
+
+def test_device_scalars_at_or_above_2pow255_fail_loudly():
+    """_dev entry points cannot inspect device scalars on the host.  Every canonical scalar is handled exactly, and so is any
+    value up to 2^254 - 2^240 (k*P for k >= r is the same point as (k mod r)*P); a larger one whose signed digits do not fit
+    the windows (anything from 2^255; from about 2^254 with 15-bit windows) would lose 2^(W c) * P, so the prepare kernel flags it and
+    the call that collects the submission fails with ZK_ERR_INVALID -- blocking and pipelined forms alike -- and the plan
+    stays usable afterwards.  Never a wrong point with ZK_OK."""
+    import torch
+    rng = np.random.default_rng(255)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (300, 5000, (1 << 17) + 77):                            # 8-, 15- and 16-bit windows
+        S = rand_fr_limbs(rng, n)
+        Pts = arithmetic_g1_points(lib, n, 12345, 7)
+        S[n // 2] = limb_row(o.R + 5)                                 # non-canonical but < 2^255: still exact
+        S[n // 3] = limb_row(o.R + (1 << 250))
+        dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
+        plan = MsmPlan(_lib.GROUP_G1, n)
+        ks = [12345 + 7 * i for i in range(n)]
+        sv = _lib.limbs_to_ints(S)
+        want = co.g1_mul(o.G1, sum(s * k for s, k in zip(sv, ks)) % o.R)
+        got = plan.run(dS.data_ptr(), dP.data_ptr(), n, st)
+        assert (int(got[0]), int(got[1])) == want
+        for v in (1 << 255, (1 << 255) - 19, (1 << 256) - 1):
+            bad = S.copy()
+            bad[7] = limb_row(v)
+            dB = torch.from_numpy(bad.view(np.int64)).cuda()
+            with pytest.raises(_lib.ZkhipError) as e:
+                plan.run(dB.data_ptr(), dP.data_ptr(), n, st)
+            assert e.value.code == _lib.ZK_ERR_INVALID
+        t_ok, t_bad = plan.submit(dS.data_ptr(), dP.data_ptr(), n, st), plan.submit(dB.data_ptr(), dP.data_ptr(), n, st)
+        with pytest.raises(_lib.ZkhipError):
+            plan.collect_limbs(t_bad)
+        ok = limbs_to_pt(plan.collect_limbs(t_ok))
+        assert ok == want
+        got = plan.run(dS.data_ptr(), dP.data_ptr(), n, st)           # the plan is not poisoned
+        assert (int(got[0]), int(got[1])) == want
+        plan.close()
+
+
+def limbs_to_pt(res):
+    from zkhip.field import limbs_to_g1
+    limbs, inf = res
+    if inf:
+        return None
+    p = limbs_to_g1(limbs)[0]
+    return (int(p[0]), int(p[1]))
+
+
+def test_chunked_submission_with_a_bad_chunk_leaves_the_plan_usable(chunk_log):
+    import torch
+    chunk_log(12)
+    rng = np.random.default_rng(256)
+    n = 3 * 4096 + 50
+    lib = _lib.load()
+    S = rand_fr_limbs(rng, n)
+    Pts = arithmetic_g1_points(lib, n, 999, 3)
+    bad = S.copy()
+    bad[2 * 4096 + 5] = limb_row((1 << 256) - 1)
+    dS, dB, dP = (torch.from_numpy(x.view(np.int64)).cuda() for x in (S, bad, Pts))
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    want = co.g1_mul(o.G1, sum(s * (999 + 3 * i) for i, s in enumerate(_lib.limbs_to_ints(S))) % o.R)
+    with pytest.raises(_lib.ZkhipError):
+        plan.run(dB.data_ptr(), dP.data_ptr(), n, st)
+    got = plan.run(dS.data_ptr(), dP.data_ptr(), n, st)
+    assert (int(got[0]), int(got[1])) == want
+    t = plan.submit(dS.data_ptr(), dP.data_ptr(), 1000, st)           # and ordinary submissions work again
+    assert limbs_to_pt(plan.collect_limbs(t)) == co.g1_mul(o.G1, sum(s * (999 + 3 * i) for i, s in enumerate(_lib.limbs_to_ints(S[:1000]))) % o.R)
+    plan.close()
+
+
+def test_invalid_host_scalars_for_device_entries():
+    """coset_shift / zinv are host-side arguments of device entry points: zero or non-canonical values are refused."""
+    import torch
+    from zkhip.device import NttPlan, fr_quotient
+    d = torch.zeros((16, 4), dtype=torch.int64, device="cuda")
+    plan = NttPlan(4)
+    st = torch.cuda.current_stream().cuda_stream
+    for bad in (0, o.R, o.R + 5):
+        with pytest.raises(_lib.ZkhipError) as e:
+            plan.run(d.data_ptr(), True, bad, st)
+        assert e.value.code == _lib.ZK_ERR_INVALID
+    plan.run(d.data_ptr(), True, 5, st)
+    with pytest.raises(_lib.ZkhipError):
+        fr_quotient(d.data_ptr(), d.data_ptr(), d.data_ptr(), d.data_ptr(), o.R, 16, st)
+    arr = _lib.ints_to_limbs([1, 2, 3, 4])
+    k = _lib.ints_to_limbs([0])
+    assert _lib.load().zk_ntt_fr(_lib.ptr(arr), 2, 1, _lib.ptr(k)) == _lib.ZK_ERR_INVALID
+    torch.cuda.synchronize()

@@ -142,13 +142,13 @@ def test_inconsistent_witness_is_rejected(toy, srs):
 def test_round_by_round_state(toy, srs):
     circuit, a, b, c, pub, pp = toy
     st = ProverState(a, b, c, pub, pp, srs)
-    round1(st)
+    round1.execute(st)
     assert st.a_poly.degree == 5 and st.proof.a_comm is not None      # n + 1 with two blinding scalars
     for i in range(4):
         assert st.a_poly.evaluate(pp.domain[i]) == a[i]                # blinding vanishes on the domain
-    round2(st)
+    round2.execute(st)
     assert st.z_poly.degree == 6 and st.z_poly.evaluate(FR(1)) == FR(1)
-    round3(st)
+    round3.execute(st)
     zeta = FR(123456789)
     t_at = st.t_lo_poly.evaluate(zeta) + zeta ** 4 * st.t_mid_poly.evaluate(zeta) + zeta ** 8 * st.t_hi_poly.evaluate(zeta)
     # t * Z_H == full constraint at a random point

@@ -150,3 +150,15 @@ def test_long_accumulation_chain_keeps_bounds(hm):
     for sel, negs, k in (([0], [1], -ks[0]), ([0, 0], [1, 1], -2 * ks[0]), ([1, 0, 0], [0, 1, 1], ks[1] - 2 * ks[0])):
         hm.hm_g1_accumulate(P(co.g1_to_arr([pts[i] for i in sel])), ctypes.c_uint32(len(sel)), P(np.array(negs, dtype=np.uint8)), P(O))
         assert co.g1_from_arr(O)[0] == co.g1_mul(o.G1, k % o.R)
+
+
+def test_sanitizer_build_is_clean():
+    """the CPU path under sanitizers.  tests/hostmath/sanitize_check links the device math compiled for
+    the host, the product's host code (csrc/pairing.hip) and the C oracle with -fsanitize=address,undefined
+    (-fno-sanitize-recover=all: any report aborts), runs a fixed workload through all three and cross-checks them."""
+    d = os.path.join(HERE, "hostmath")
+    subprocess.check_call(["make", "-s", "-C", d, "sanitize_check"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([os.path.join(d, "sanitize_check")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith("sanitize ok")

@@ -65,3 +65,44 @@ def test_groth16_verify_equation_on_the_toy_proof():
     assert o.groth16_verify(d["proof_A"], d["proof_B"], d["proof_C"], d["s11"], d["s13"], d["s21"], rx_pub)
     bad = [(o.g1_double(d["proof_A"]), d["proof_B"])] + pairs[1:]
     assert not check(bad)
+
+
+def test_off_curve_and_non_canonical_inputs_are_rejected():
+    """py_ecc's pairing asserts is_on_curve(Q, b2) and is_on_curve(P, b) (bn128_pairing.py); the library refuses the same
+    inputs with ZK_ERR_INVALID (the Python facade turns that into the reference's AssertionError), and the oracle's
+    restatement carries the assertions too.  The all-zero encoding stays the point at infinity."""
+    import pytest
+    from zkhip.field import FQ, FQ2, ec_pairing, pairing_check
+    lib = _lib.load()
+    out = np.zeros(48, dtype=np.uint64)
+    ok = ctypes.c_int(-1)
+    g1, g2 = co.g1_to_arr([o.G1]), co.g2_to_arr([o.G2])
+    bad_g1 = g1.copy()
+    bad_g1[0, 4] += 1                                       # (1, 3): y^2 != x^3 + 3
+    bad_g2 = g2.copy()
+    bad_g2[0, 8] ^= 1                                       # y.c0 with its low bit flipped
+    big_g1 = g1.copy()
+    big_g1[0, :4] = co.to_limbs([o.P + 1])[0]               # x = p + 1: the residue is on the curve, the encoding is not canonical
+    for p_arr, q_arr in ((bad_g1, g2), (g1, bad_g2), (big_g1, g2)):
+        assert lib.zk_pairing(_lib.ptr(p_arr), _lib.ptr(q_arr), _lib.ptr(out)) == _lib.ZK_ERR_INVALID
+        assert b"canonical point" in lib.zk_last_error()
+        assert lib.zk_pairing_check(_lib.ptr(p_arr), _lib.ptr(q_arr), 1, ctypes.byref(ok)) == _lib.ZK_ERR_INVALID
+    # a valid pair in front does not let a bad one through
+    two_p, two_q = np.concatenate([g1, bad_g1]), np.concatenate([g2, g2])
+    assert lib.zk_pairing_check(_lib.ptr(two_p), _lib.ptr(two_q), 2, ctypes.byref(ok)) == _lib.ZK_ERR_INVALID
+    # facade: the reference's AssertionError
+    off1 = (FQ(1), FQ(3))
+    off2 = (FQ2([o.G2[0][0], o.G2[0][1]]), FQ2([o.G2[1][0] ^ 1, o.G2[1][1]]))
+    good2 = (FQ2(list(o.G2[0])), FQ2(list(o.G2[1])))
+    with pytest.raises(AssertionError):
+        ec_pairing(good2, off1)
+    with pytest.raises(AssertionError):
+        ec_pairing(off2, (FQ(1), FQ(2)))
+    with pytest.raises(AssertionError):
+        pairing_check([((FQ(1), FQ(2)), good2), (off1, good2)])
+    assert ec_pairing(good2, None) == ec_pairing(None, (FQ(1), FQ(2)))    # infinity still gives the identity
+    # the oracle mirrors the assertion
+    with pytest.raises(AssertionError):
+        o.pairing(o.G2, (1, 3))
+    with pytest.raises(AssertionError):
+        o.pairing(((o.G2[0][0], o.G2[0][1]), (o.G2[1][0] ^ 1, o.G2[1][1])), o.G1)

@@ -35,10 +35,7 @@ def main():
     for it in range(a.iters):
         g2 = rng.random() < 0.25
         chunk = int(rng.choice([0, 12, 14, 18]))
-        if chunk:
-            os.environ["ZK_MSM_CHUNK_LOG"] = str(chunk)
-        else:
-            os.environ.pop("ZK_MSM_CHUNK_LOG", None)
+        _lib.check(_lib.load().zk_test_set_msm_chunk_log(chunk))
         limit = 1 << (chunk or 22)
         cap = n2max if g2 else nmax
         n = int(min(cap, max(1, int(2 ** rng.uniform(0, np.log2(cap))) + int(rng.integers(0, 3)))))
