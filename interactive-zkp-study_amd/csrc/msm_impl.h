@@ -613,30 +613,45 @@ __global__ __launch_bounds__(HEAVY_CT) void msm_heavy_combine_kernel(SortBufs B,
 //   of all lower levels together need (s+1) * (half >> s) <= half additions: one EC addition per
 //   thread per step, depth = number of levels.
 // Afterwards O_l = x[2^l] and T = x[0] (per block for the block kernel, per window at the end).
+// Block phase: ONE wavefront per block of 2^BL buckets (BL >= 6).  Lane t first runs steps 0 .. m-1 (m = BL - 6) of the
+// algorithm on its own 2^m consecutive buckets, serially and with no synchronisation -- every lane busy, 2 * 2^m - 2 - m additions --
+// then the 64 lanes run steps m .. BL-1 over the block together: 11 + 8 addition steps for a 512-bucket block, one wavefront per
+// SIMD.  (A 256-thread workgroup per block with one task per thread and step keeps (s+1) * 2^(BL-1-s) threads busy at step s -- 44 %
+// over the nine steps -- at four wavefronts per SIMD: the whole reduce stage of a 2^20-point MSM went 0.256 -> 0.225 ms (G1) and
+// 0.83 -> 0.69 ms (G2); blocks of 256 or 1024 buckets are slower: profiles/r02_experiments.md.)
 template <class F>
-__global__ __launch_bounds__(256, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_reduce_block_kernel(Xyzz<F> *x, uint32_t BL) {
+__device__ __forceinline__ void reduce_task(Xyzz<F> *base, uint32_t s, uint32_t sh, uint32_t q) {
+    const uint32_t grp = q >> sh, i = q & ((1u << sh) - 1u);
+    uint32_t dst, src;
+    if (grp == s) {  // pair tree, level s -> s+1
+        dst = i << (s + 1);
+        src = dst + (1u << s);
+    } else {  // odd tree of level grp, its step k
+        const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
+        dst = (2 * j + 1) << l;
+        src = (2 * (j + (1u << k)) + 1) << l;
+    }
+    Xyzz<F> a = base[dst];
+    const Xyzz<F> b = base[src];
+    xyzz_add(a, b);
+    base[dst] = a;
+}
+template <class F>
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 2 : 1)) void msm_reduce_wave_kernel(Xyzz<F> *x, uint32_t BL) {
     Xyzz<F> *blk = x + ((size_t)blockIdx.x << BL);
-    const uint32_t t = threadIdx.x;
-    for (uint32_t s = 0; s < BL; s++) {
-        const uint32_t sh = BL - 1 - s, per = 1u << sh;  // additions per tree at this step
-        const uint32_t ntasks = (s + 1) * per;
-        for (uint32_t q = t; q < ntasks; q += blockDim.x) {
-            const uint32_t grp = q >> sh, i = q & (per - 1u);
-            uint32_t dst, src;
-            if (grp == s) {  // pair tree, level s -> s+1
-                dst = i << (s + 1);
-                src = dst + (1u << s);
-            } else {  // odd tree of level grp, its step k
-                const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
-                dst = (2 * j + 1) << l;
-                src = (2 * (j + (1u << k)) + 1) << l;
-            }
-            Xyzz<F> a = blk[dst];
-            const Xyzz<F> b = blk[src];
-            xyzz_add(a, b);
-            blk[dst] = a;
-        }
-        __syncthreads();  // the workgroup's waves share one CU (one L1): workgroup-scope visibility
+    const uint32_t lane = threadIdx.x, m = BL - 6;
+    Xyzz<F> *mine = blk + ((size_t)lane << m);
+    for (uint32_t s = 0; s < m; s++) {
+        const uint32_t sh = m - 1 - s, ntasks = (s + 1) << sh;
+#pragma unroll 1
+        for (uint32_t q = 0; q < ntasks; q++) reduce_task(mine, s, sh, q);
+    }
+    __syncthreads();
+    for (uint32_t s = m; s < BL; s++) {
+        const uint32_t sh = BL - 1 - s, ntasks = (s + 1) << sh;
+#pragma unroll 1
+        for (uint32_t q = lane; q < ntasks; q += 64) reduce_task(blk, s, sh, q);
+        __syncthreads();
     }
 }
 
@@ -1013,7 +1028,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                            L.arena.template as<Xyzz<F>>());
         mark(L, 3);
         const uint32_t levels = FIX_C - 1, BL = 9;
-        hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3(FIX_NB >> BL), dim3(1u << (BL - 1)), 0, ls, L.arena.template as<Xyzz<F>>(), BL);
+        hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3(FIX_NB >> BL), dim3(64), 0, ls, L.arena.template as<Xyzz<F>>(), BL);
         for (uint32_t step = 0; step < levels - BL; step++) {
             const uint32_t ntasks = (step + 1 + BL) << (levels - BL - 1 - step);
             hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3((ntasks + 255) / 256, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(),
@@ -1098,8 +1113,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         {
             Xyzz<F> *ar = L.arena.template as<Xyzz<F>>();
             const uint32_t BL = std::min<uint32_t>(9, levels);
-            const uint32_t threads = std::max<uint32_t>(64, 1u << (BL - 1));
-            hipLaunchKernelGGL((msm_reduce_block_kernel<F>), dim3((W * nb) >> BL), dim3(threads), 0, L.stream, ar, BL);
+            hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3((W * nb) >> BL), dim3(64), 0, L.stream, ar, BL);
             hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, L.stream, ar, out_dev(L), nb, BL, levels);
         }
         mark(L, 4);
