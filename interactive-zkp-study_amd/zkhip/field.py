@@ -50,16 +50,23 @@ class _PrimeField:
 
     __rmul__ = __mul__
 
+    @classmethod
+    def _inv0(cls, v):
+        """py_ecc's prime_field_inv: the modular inverse extended by inv0(0) = 0 -- the reference's FR(x) / FR(0) is FR(0),
+        not an exception (py_ecc/utils.py, after draft-irtf-cfrg-hash-to-curve section 4)."""
+        v %= cls.field_modulus
+        return pow(v, -1, cls.field_modulus) if v else 0
+
     def __truediv__(self, other):
-        return type(self)(self.n * pow(self._coerce(other) % self.field_modulus, -1, self.field_modulus))
+        return type(self)(self.n * self._inv0(self._coerce(other)))
 
     def __rtruediv__(self, other):
-        return type(self)(self._coerce(other) * pow(self.n, -1, self.field_modulus))
+        return type(self)(self._coerce(other) * self._inv0(self.n))
 
     def __pow__(self, e):
         e = int(e)
         if e < 0:
-            return type(self)(pow(pow(self.n, -1, self.field_modulus), -e, self.field_modulus))
+            return type(self)(pow(self._inv0(self.n), -e, self.field_modulus))
         return type(self)(pow(self.n, e, self.field_modulus))
 
     def __neg__(self):

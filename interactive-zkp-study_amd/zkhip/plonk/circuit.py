@@ -60,6 +60,10 @@ class Circuit:
             sigma[p1], sigma[p2] = sigma[p2], sigma[p1]
         return sigma
 
+    def compute_witness(self, assignments):
+        """Left to subclasses / factory methods, as in the reference (circuit.py:238-252)."""
+        raise NotImplementedError("implement in a subclass or use a factory method such as x3_plus_x_plus_5_eq_35()")
+
     @staticmethod
     def x3_plus_x_plus_5_eq_35():
         """The reference's toy circuit x^3 + x + 5 = 35 at x = 3 (circuit.py:286-331):

@@ -31,14 +31,16 @@ def compute_accumulator(a_vals, b_vals, c_vals, sigma, n, domain, beta, gamma):
         a, b, c, w = int(a_vals[i]), int(b_vals[i]), int(c_vals[i]), int(domain[i])
         nums.append((a + be * w + ga) * (b + be * 2 * w + ga) % r * (c + be * 3 * w + ga) % r)
         dens.append((a + be * int(s1[i]) + ga) * (b + be * int(s2[i]) + ga) % r * (c + be * int(s3[i]) + ga) % r)
+    # batch inversion with py_ecc's convention inv0(0) = 0 (FR(x) / FR(0) is FR(0) in the reference): a zero denominator is
+    # left out of the running product and its "inverse" is 0, so z is 0 from that row on, as in the reference's loop
     pref = [1]
     for d in dens:
-        pref.append(pref[-1] * d % r)
-    inv = pow(pref[-1], -1, r) if dens else 1
+        pref.append(pref[-1] * (d or 1) % r)
+    inv = pow(pref[-1], -1, r)
     inv_dens = [0] * len(dens)
     for i in range(len(dens) - 1, -1, -1):
-        inv_dens[i] = pref[i] * inv % r
-        inv = inv * dens[i] % r
+        inv_dens[i] = pref[i] * inv % r if dens[i] else 0
+        inv = inv * (dens[i] or 1) % r
     z = [1]
     for i in range(n - 1):
         z.append(z[-1] * nums[i] % r * inv_dens[i] % r)

@@ -4,6 +4,10 @@ from ..permutation import K1, K2
 from ..polynomial import Polynomial
 
 COSET_K = 5
+# round3.py:140-147 raises ValueError with this (Korean) text when C(x) is not a multiple of Z_H(x); the reference's own test
+# matches on it (tests/plonk/test_prover.py:746), so the text is part of the error behaviour.  English gloss appended.
+NOT_DIVISIBLE = ("제약 다항식이 Z_H(x)로 나누어 떨어지지 않습니다. 회로 또는 witness에 오류가 있습니다. "
+                 "(the constraint polynomial is not divisible by Z_H(x): circuit or witness is inconsistent)")
 
 
 def pad_rows(vals, n):

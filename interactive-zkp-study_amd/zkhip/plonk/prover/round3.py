@@ -9,7 +9,7 @@ from ..kzg import commit
 from ..permutation import K1, K2
 from ..polynomial import Polynomial
 from ..utils import coset_fft, coset_ifft
-from .common import COSET_K
+from .common import COSET_K, NOT_DIVISIBLE
 
 
 def _coset_evals(poly, size, omega_big):
@@ -51,7 +51,7 @@ def execute(state):
         t_evals.append(total * zh_inv[i % step] % R)
     t_coeffs = [int(v) for v in coset_ifft(t_evals, w_big, FR(COSET_K))]
     if any(t_coeffs[3 * n + 6:]):
-        raise ValueError("constraint polynomial is not divisible by Z_H: circuit or witness is inconsistent")
+        raise ValueError(NOT_DIVISIBLE)
     t_coeffs = t_coeffs[:max(3 * n, 3 * n + 6)]
     while len(t_coeffs) > 3 * n and t_coeffs[-1] == 0:
         t_coeffs.pop()

@@ -24,6 +24,7 @@ from ..device import FrVec, MsmPlan, NttPlan, plonk_quotient
 from ..field import FR, CURVE_ORDER as R, get_root_of_unity, limbs_to_g1
 from .permutation import K1, K2
 from .prover import COSET_K, Proof, linearisation_scalars
+from .prover.common import NOT_DIVISIBLE
 from .transcript import Transcript
 
 PAD = 8  # slack coefficients behind the n of every polynomial buffer (blinding adds up to 3, t_hi up to 6)
@@ -266,7 +267,7 @@ class DevicePlonk:
                        self.zh_inv, al, be, ga, size, st)                         # one pass over the 15 vectors (zk_plonk_quotient_dev)
         self.ntt_big.run(tot.data_ptr(), True, COSET_K, st)
         if bool(tot[3 * n + 6:].any()):
-            raise ValueError("constraint polynomial is not divisible by Z_H: circuit or witness is inconsistent")
+            raise ValueError(NOT_DIVISIBLE)
         t_parts = []
         for k, (lo, hi) in enumerate(((0, n), (n, 2 * n), (2 * n, 3 * n + 6))):
             part = B["t%d" % k]

@@ -28,8 +28,6 @@ def verify(proof, public_inputs, preprocessed, srs):
     a_e, b_e, c_e = FR(pr.a_eval), FR(pr.b_eval), FR(pr.c_eval)
     s1_e, s2_e, zw_e, r_e = FR(pr.s_sigma1_eval), FR(pr.s_sigma2_eval), FR(pr.z_omega_eval), FR(pr.r_eval)
     zh_zeta, l1_zeta, perm_z, perm_s3, r0 = linearisation_scalars(alpha, beta, gamma, zeta, n, omega, a_e, b_e, c_e, s1_e, s2_e, zw_e)
-    if zh_zeta == FR(0):
-        return False
     zeta_n = zeta ** n
     v2, v3, v4, v5, v6 = v ** 2, v ** 3, v ** 4, v ** 5, v ** 6
     # e = t(zeta) + v r + v^2 a + v^3 b + v^4 c + v^5 s1 + v^6 s2 + u z_w   with t(zeta) = r / Z_H(zeta)

@@ -130,6 +130,21 @@ def g1_short(point):
     return "(%s, %s)" % (_shorten(str(int(point[0]))), _shorten(str(int(point[1]))))
 
 
+def g2_short(point):
+    """plonk_serializers.py:269-280: only the x coordinate of a G2 point is shown."""
+    if point is None:
+        return "∞"
+    return "(%s+%si, ...)" % (_shorten(str(int(point[0].coeffs[0]))), _shorten(str(int(point[0].coeffs[1]))))
+
+
+def fr_short(val):
+    """plonk_serializers.py:283-289 (scalars keep ten digits before they are shortened)."""
+    if val is None:
+        return "None"
+    s = str(int(val))
+    return s if len(s) <= 10 else s[:4] + "..." + s[-4:]
+
+
 # Groth16 side (app.py:967-1001, 1264-1311): points persist as nested int lists.
 def turn_g1_int(point):
     return None if point is None else [int(point[0]), int(point[1])]

@@ -518,9 +518,7 @@ def verify(proof, public_inputs, preprocessed, srs):
         F = ec_add(F, ec_mul(comm, v_pow))
         v_pow = v_pow * v % R
     r_eval = pf.r_eval % R
-    if zh_zeta == 0:
-        raise ZeroDivisionError("Z_H(zeta) = 0")                  # FR division by zero in the reference (verifier.py:164)
-    t_eval = r_eval * pr.fr_inv(zh_zeta) % R
+    t_eval = r_eval * pr.fr_inv(zh_zeta) % R                     # verifier.py:164; FR division: inv0(0) = 0 if zeta lies on the domain
     e_scalar = (t_eval + v * r_eval) % R
     v_pow = v * v % R
     for val in (a_e, b_e, c_e, s1_e, s2_e):

@@ -203,7 +203,9 @@ def ec_neg(pt):
 
 # ----------------------------------------------------------------------------- F_r helpers
 def fr_inv(a):
-    return pow(a % R, -1, R)
+    """FR(1) / FR(a) as py_ecc computes it: prime_field_inv extends the inverse by inv0(0) = 0 (py_ecc/utils.py)."""
+    a %= R
+    return pow(a, -1, R) if a else 0
 
 
 def get_root_of_unity(n):

@@ -263,6 +263,22 @@ def test_groth16_verify_true_and_tampered(pipeline):
     assert verify(p["prf_A"], p["prf_B"], p["prf_C"], p["s11"], p["s13"], p["s21"], wrong_pub) is False
 
 
+def test_public_curve_constants_through_the_backend():
+    """The external anchors of tests/test_oracle.py::test_public_curve_constants, computed by the GPU backend: 2*G1 of
+    alt_bn128 (EIP-196 vectors / py_ecc.bn128.double(G1)) by addition, scalar multiplication, a two-term MSM and the
+    fixed-base batch; the published 2^28-th root of unity behind every NTT domain."""
+    from zkhip.field import fixed_base_mul, msm_g1
+    two_g = (FQ(1368015179489954701390400359078579693043519447331113978918064868415326638035),
+             FQ(9918110051302171585080402603319702774565515993150576347155970296011118125764))
+    assert ec_add(G1, G1) == two_g and ec_mul(G1, 2) == two_g
+    assert msm_g1([FR(1), FR(1)], [G1, G1]) == two_g and fixed_base_mul(G1, [2, CURVE_ORDER + 2])[0] == two_g
+    w28 = 19103219067921713944291392827692070036145651957329286315305642004821462161904
+    assert int(get_root_of_unity(1 << 28)) == w28
+    n = 16
+    ev = fft([FR(0), FR(1)] + [FR(0)] * (n - 2), get_root_of_unity(n))       # p(x) = x evaluated on the domain: the powers of omega_16
+    assert [int(v) for v in ev] == [pow(w28, (1 << 24) * i, CURVE_ORDER) for i in range(n)]
+
+
 def test_verifiers_refuse_off_curve_proof_points(pipeline, srs_small):
     """py_ecc's pairing asserts is_on_curve for both arguments, so the reference's verifiers raise on a proof element that
     is not a curve point; the backend refuses the same inputs (AssertionError from the facade, ZK_ERR_INVALID at the ABI)

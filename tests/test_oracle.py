@@ -47,6 +47,24 @@ def test_constants_appendix_a():
     assert o.srs_tau(42) == 8365577799539384663899794442022354891237484320765090705979616311134436098119
 
 
+def test_public_curve_constants():
+    """Known answers that do not come from this repo: public constants of the curve and field the reference uses through
+    py_ecc's bn128 (= Ethereum's alt_bn128).  The reference's own tests hold no EC coordinate, so
+    these are the external anchors of the G1 arithmetic and of the NTT's root of unity:
+      * 2*G1, the doubling of the generator (1, 2), as published with the EIP-196 ecAdd / ecMul test vectors and returned by
+        py_ecc.bn128.double(G1);
+      * omega_{2^28} = 5^((r-1)/2^28), the 2^28-th root of unity every BN254 toolchain ships for generator 5 (snarkjs /
+        ffjavascript, gnark) -- get_root_of_unity(n) (zkp/plonk/field.py:178-180) is its 2^(28-log n)-th power."""
+    two_g = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+             9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    assert o.g1_double(o.G1) == two_g and o.g1_add(o.G1, o.G1) == two_g and o.g1_multiply(o.G1, 2) == two_g
+    assert co.g1_mul(o.G1, 2) == two_g                                   # the C oracle agrees
+    w28 = 19103219067921713944291392827692070036145651957329286315305642004821462161904
+    assert o.get_root_of_unity(1 << 28) == w28
+    for log_n in (2, 12, 20, 22):
+        assert o.get_root_of_unity(1 << log_n) == pow(w28, 1 << (28 - log_n), R)
+
+
 def test_reference_comment_kats():
     """F_r known-answers that survive in zkp/groth16/backend.py:355,363 (with pub = [0, 1])."""
     d = o.toy_groth16()

@@ -26,6 +26,9 @@ def test_scalars_points_polys_roundtrip(golden_dir):
     assert ser.serialize_poly(poly) == ["1", "0", "5"] and ser.deserialize_poly(["1", "0", "5"]) == poly
     assert ser.deserialize_fr_list(ser.serialize_fr_list([FR(3), FR(4)])) == [FR(3), FR(4)]
     assert ser.g1_short(None) == "∞" and ser.g1_short((FQ(1), FQ(2))) == "(1, 2)"
+    from zkhip.field import G2
+    assert ser.g2_short(None) == "∞" and ser.g2_short(G2) == "(1085...2781+1155...5634i, ...)"
+    assert ser.fr_short(None) == "None" and ser.fr_short(FR(1234567890)) == "1234567890" and ser.fr_short(FR(12345678901)) == "1234...8901"
     assert ser.g1_from_ints(ser.turn_g1_int(p)) == p and ser.g2_from_ints(ser.turn_g2_int(q)) == q
 
 
