@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """Collect the measurement artifacts kept under profiles/ (run from the repo root on the GPU box).
 
-    python3 tools/collect_profiles.py run  [--round r01]   # on the GPU box: bench line + rocprofv3 passes -> gpurun_out/prof_<round>/
-    python3 tools/collect_profiles.py fold [--round r01]   # anywhere: gpurun_out/prof_<round>/ -> profiles/<round>_*
+    python3 tools/collect_profiles.py run  [--round r02]   # on the GPU box: bench line + rocprofv3 passes -> gpurun_out/prof_<round>/
+    python3 tools/collect_profiles.py fold [--round r02]   # anywhere: gpurun_out/prof_<round>/ -> profiles/<round>_*
 
 `run` starts each program directly after `rocprofv3 ... --` (no shell/env hop) and keeps the
 counter passes (`--pmc`) separate from the kernel trace, one counter per pass."""
 import argparse, csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound"]
+BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--sizes", "", "--sizes-ntt", ""]
 
 
 def sh(cmd, log):
@@ -102,6 +102,6 @@ def fold(rnd):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("mode", choices=["run", "fold"])
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
     a = ap.parse_args()
     sys.exit(run(a.round) if a.mode == "run" else fold(a.round))
