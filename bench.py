@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="N > 1 with fewer than N devices: the ranks share the visible devices and talk over gloo "
                     "(checks the N-rank code path; the numbers are not a scaling measurement)")
     ap.add_argument("--dry-launch", action="store_true", help="N > 1: print the child command instead of running it")
+    ap.add_argument("--exchange", choices=["rccl", "host"], default="rccl", help="N > 1: how the 128-byte MSM partials travel: one RCCL all-gather per "
+                    "step on a side stream (default; what north_star names), or a host-side gloo all-gather of the host-resident partials "
+                    "(no GPU work at all; for comparison)")
     ap.add_argument("--sizes", default="24,26", help="N = 1: log2 sizes of the extra one-GPU G1 MSM measurements (BASELINE.json metric names 2^20/2^24/2^26; '' = skip)")
     ap.add_argument("--sizes-ntt", default="24", help="N = 1: log2 sizes of the extra NTT measurements ('' = skip)")
     args = ap.parse_args()
@@ -103,12 +106,17 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    if args.gpus > 1 or args.force_dist:
+        # The multi-rank path adds the exchange's side stream and RCCL's own streams to the three lane streams: give the HIP
+        # runtime eight hardware queues instead of its default four, so that no two of them have to share one (read when the
+        # runtime initialises, i.e. before the first HIP call below; 1.45 -> 1.43 ms per step on one rank over RCCL).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import torch.distributed as dist
     from zkhip import _lib
     from zkhip.device import MsmPlan, NttPlan
-    from zkhip.distributed import sharded_msm
+    from zkhip.distributed import sharded_msm, sharded_msm_start
     from zkhip.field import G1, ec_mul, limbs_to_g1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +136,12 @@ def main():
     _lib.check(lib.zk_set_device(dev_index))
     dev = torch.device("cuda", dev_index)
     dist_on = world > 1 or args.force_dist
+    n = 1 << args.log_n
+    # The MSM plan first: HIP maps streams to its few hardware queues in creation order, and two lanes that end up on one
+    # queue run their kernels one after the other (measured: 1.50 instead of 1.38 ms per step when the process group's
+    # streams were created first).  The lanes take the first queues; RCCL's streams then share with whatever is left.
+    plan = MsmPlan(_lib.GROUP_G1, n)
+    plan.set_profiling(True)
     # collectives: RCCL ("nccl") between GPUs; gloo when ranks share a device (RCCL refuses two ranks on one GPU), in which
     # case the few bytes of every exchange are staged through the host (zkhip.distributed handles both)
     cdev = None if rehearsal else dev                                  # where control tensors and partials live
@@ -139,7 +153,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         world = dist.get_world_size()                                  # n_gpus of the line = what the process group reports
-    n = 1 << args.log_n
+        host_group = dist.new_group(backend="gloo") if (args.exchange == "host" and not rehearsal) else None
 
     # ---- synthetic workload, generated once and left resident in HBM
     rng = np.random.default_rng(0x5EEDB254 + rank)
@@ -152,33 +166,51 @@ def main():
     d_points = torch.from_numpy(points.view(np.int64)).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    plan = MsmPlan(_lib.GROUP_G1, n)
-    plan.set_profiling(True)
-
     # Steps are pipelined (zk_msm_submit / zk_msm_collect, plan.max_in_flight() = 3 outstanding): every
     # submission runs in its own workspace and stream, so consecutive MSMs overlap on the GPU and the
     # ~0.2 ms host fold of step k hides behind the following steps, as in a prover issuing its MSMs back to
     # back.  Every step's pipeline, read-back, fold (and for N > 1 its all-gather) completes inside the
     # timed region.
-    def finish(ticket):
-        if not dist_on:
-            return plan.collect_limbs(ticket)
-        return sharded_msm(_lib.GROUP_G1, plan.collect_partial(ticket), device=cdev)
-
     depth = plan.max_in_flight() if n <= (1 << 22) else 1   # larger MSMs already run as 2^22-point chunks through all lanes
+    xdev, xgroup = (None, host_group) if (dist_on and host_group is not None) else (cdev, None)
 
     def run_steps(k, stage_acc=None):
-        res, pending = None, []
-        for _ in range(k):
+        """k complete steps: every step's pipeline, read-back, host fold and -- for N > 1 -- its exchange and rank-order fold
+        finish before this returns.  A lane is refilled as soon as its result has been collected; the exchange of the
+        collected partial is started after that refill and waited for one step later (zkhip.distributed.PartialGather), so
+        neither the collective nor the Python around it sits between a lane finishing and its next submission."""
+        res, pending, exchange, submitted = None, [], None, 0
+
+        def submit():
+            nonlocal submitted
             pending.append(plan.submit(d_scalars.data_ptr(), d_points.data_ptr(), n, stream))
-            if len(pending) == depth:
-                res = finish(pending.pop(0))
-                if stage_acc is not None:
-                    stage_acc += np.array(plan.stage_ms())
-        while pending:
-            res = finish(pending.pop(0))
+            submitted += 1
+
+        def collect():
+            out = plan.collect_partial(pending.pop(0)) if dist_on else plan.collect_limbs(pending.pop(0))
             if stage_acc is not None:
-                stage_acc += np.array(plan.stage_ms())
+                np.add(stage_acc, plan.stage_ms(), out=stage_acc)
+            return out
+
+        def post(out):
+            nonlocal res, exchange
+            if not dist_on:
+                res = out
+                return
+            started = sharded_msm_start(_lib.GROUP_G1, out, device=xdev, group=xgroup)
+            if exchange is not None:
+                res = exchange.result()
+            exchange = started
+
+        while submitted < k and len(pending) < depth:
+            submit()
+        while pending:
+            out = collect()
+            if submitted < k:
+                submit()
+            post(out)
+        if exchange is not None:
+            res = exchange.result()
         return res
 
     def fence():
@@ -561,7 +593,8 @@ def main():
             "extra": extra,
         }
         if dist_on:
-            line["config"]["collectives"] = "gloo, ranks share %d device(s): REHEARSAL, not a scaling measurement" % visible if rehearsal else "RCCL (nccl backend)"
+            line["config"]["collectives"] = ("gloo, ranks share %d device(s): REHEARSAL, not a scaling measurement" % visible if rehearsal else
+                                             "RCCL (nccl backend)" + ("; MSM partials over a host-side gloo group (--exchange host)" if host_group is not None else ""))
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

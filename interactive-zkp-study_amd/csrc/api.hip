@@ -314,6 +314,7 @@ struct zk_ntt_plan {
 };
 struct zk_frvec {
     FrVecScratch impl;
+    int device = 0;  // the scratch buffers are allocated on the device that was current at creation
 };
 
 extern "C" {
@@ -595,6 +596,7 @@ int zk_frvec_create(zk_frvec **ws) {
         int rc = require_device();
         if (rc) return rc;
         *ws = new zk_frvec;
+        ZK_HIP(hipGetDevice(&(*ws)->device));
         return ZK_OK;
     });
 }
@@ -606,6 +608,7 @@ int zk_fr_scale_powers_dev(zk_frvec *ws, void *d_data, size_t n, const uint64_t 
     return guarded([&] {
         if (!ws || !base || (n && !d_data)) return invalid("zk_fr_scale_powers_dev: null pointer");
         if (!scalars_canonical(base, 1)) return invalid("zk_fr_scale_powers_dev: base not canonical (>= r)");
+        if (int rc = check_plan_device(ws->device, "zk_fr_scale_powers_dev")) return rc;
         ws->impl.scale_powers(d_data, n, base, (hipStream_t)stream);
         return ZK_OK;
     });
@@ -614,6 +617,7 @@ int zk_fr_scan_dev(zk_frvec *ws, void *d_data, size_t n, int op, int reverse, vo
     return guarded([&] {
         if (!ws || (n && !d_data)) return invalid("zk_fr_scan_dev: null pointer");
         if (op != 0 && op != 1) return invalid("zk_fr_scan_dev: op must be 0 (sum) or 1 (product)");
+        if (int rc = check_plan_device(ws->device, "zk_fr_scan_dev")) return rc;
         ws->impl.scan(d_data, n, op == 1, reverse != 0, (hipStream_t)stream);
         return ZK_OK;
     });

@@ -40,6 +40,17 @@ __device__ __forceinline__ Fr ld_canon(const uint32_t *p) {
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     return fe_from_words<FrTag>(w);
 }
+// the same for a normalised value already known to be < 2r (every product, every reduced butterfly sum): one conditional
+// subtraction instead of the four of fe_reduce_full
+__device__ __forceinline__ void st_canon_2r(uint32_t *p, Fr v) {
+    uint32_t w[8];
+    ZK_DBG_ASSERT(v.vb <= 2 && v.lmax <= 1, "st_canon_2r: value must be normalised and < 2r");
+    fe_cond_sub<1>(v);
+    fe_to_words(v, w);
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
 __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
     uint32_t w[8];
     fe_to_words(fe_reduce_full(v), w);
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             Fr x = lds_ld(data, tile, (jpos << g) | c);
             if (P.apply_scale) x = fe_mul(x, scale);
             const size_t oidx = (size_t)(k1_base + c) + (((size_t)kmid + ((size_t)k << lmid_tot)) << P.l1);
-            st_canon(out_c + oidx * 8, x);
+            st_canon_2r(out_c + oidx * 8, x);
         }
     }
 }
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256) void fr_scale_powers_kernel(uint32_t *__restri
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Fr w = fe_mul(A[i & ((1u << lh) - 1u)], B[i >> lh]);
-    st_canon(x + i * 8, fe_mul(ld_canon(x + i * 8), w));
+    st_canon_2r(x + i * 8, fe_mul(ld_canon(x + i * 8), w));
 }
 
 // x[b * cols + k] *= w^((row0 + b) * k) for b < rows, k < cols, with w^e = A[e & mask] * B[e >> lh] (two-level table of the

@@ -24,14 +24,32 @@ def shard_range(n, rank, world_size):
 
 
 _gather_ctx = {}
+_RING = 4   # exchanges that may be in flight per (device, size, world)
 
 
-def all_gather_partials(partial, device=None, group=None):
-    """partial: uint64[L] on the host -> uint64[world, L] (rank order) on every rank.
+class PartialGather:
+    """One all-gather of a host partial, started by all_gather_partials_start and finished by .result().
 
-    On a GPU the copy-in, the collective and the copy-out run on a side stream of their own, so they wait
-    for nothing the caller has queued on its compute stream since (bench.py keeps the next MSM in flight
-    while the previous step's partials are exchanged); buffers are allocated once per (device, size)."""
+    On a GPU the copy-in, the collective (RCCL) and the copy-out are only ENQUEUED by the start call -- on a side stream of
+    their own, so they wait for nothing the caller has queued on its compute stream since -- and .result() waits for the
+    copy-out.  A caller that keeps MSMs in flight starts the exchange of step k and collects the one of step k-1: the
+    collective's kernel has to find its way onto CUs that the MSM kernels keep full, and that latency (0.2 ms per step on one
+    rank when waited for at once) then hides behind the next MSM instead of stalling the submission loop."""
+
+    def __init__(self, slot=None, event=None, value=None):
+        self._slot, self._event, self._value = slot, event, value
+
+    def result(self):
+        """-> uint64[world, L] (rank order)."""
+        if self._value is None:
+            self._event.synchronize()
+            self._value = self._slot["h_out"].numpy().view(np.uint64).reshape(self._slot["world"], -1).copy()
+            self._slot["busy"] = False
+        return self._value
+
+
+def all_gather_partials_start(partial, device=None, group=None):
+    """partial: uint64[L] on the host -> PartialGather.  Buffers are allocated once per (device, size, world), as a ring."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -40,23 +58,35 @@ def all_gather_partials(partial, device=None, group=None):
         t = torch.from_numpy(src.copy())
         out = torch.empty(world * t.numel(), dtype=torch.int64)  # flat: gloo and RCCL both accept it
         dist.all_gather_into_tensor(out, t, group=group)
-        return out.numpy().view(np.uint64).reshape(world, -1)
+        return PartialGather(value=out.numpy().view(np.uint64).reshape(world, -1))
     key = (str(device), src.size, world)
     ctx = _gather_ctx.get(key)
     if ctx is None:
-        ctx = {"stream": torch.cuda.Stream(device=device, priority=-1),  # ahead of the bulk MSM kernels
-               "h_in": torch.empty(src.size, dtype=torch.int64).pin_memory(),
-               "d_in": torch.empty(src.size, dtype=torch.int64, device=device),
-               "d_out": torch.empty(world * src.size, dtype=torch.int64, device=device),
-               "h_out": torch.empty(world * src.size, dtype=torch.int64).pin_memory()}
+        ctx = {"stream": torch.cuda.Stream(device=device, priority=-1), "next": 0, "slots": []}  # ahead of the bulk MSM kernels
+        for _ in range(_RING):
+            ctx["slots"].append({"h_in": torch.empty(src.size, dtype=torch.int64).pin_memory(),
+                                 "d_in": torch.empty(src.size, dtype=torch.int64, device=device),
+                                 "d_out": torch.empty(world * src.size, dtype=torch.int64, device=device),
+                                 "h_out": torch.empty(world * src.size, dtype=torch.int64).pin_memory(),
+                                 "event": torch.cuda.Event(), "busy": False, "world": world})
         _gather_ctx[key] = ctx
-    ctx["h_in"].numpy()[:] = src
+    slot = ctx["slots"][ctx["next"]]
+    ctx["next"] = (ctx["next"] + 1) % _RING
+    if slot["busy"]:
+        raise RuntimeError("all_gather_partials_start: more than %d exchanges in flight; collect the oldest first" % _RING)
+    slot["busy"] = True
+    slot["h_in"].numpy()[:] = src
     with torch.cuda.stream(ctx["stream"]):
-        ctx["d_in"].copy_(ctx["h_in"], non_blocking=True)
-        dist.all_gather_into_tensor(ctx["d_out"], ctx["d_in"], group=group)
-        ctx["h_out"].copy_(ctx["d_out"], non_blocking=True)
-    ctx["stream"].synchronize()
-    return ctx["h_out"].numpy().view(np.uint64).reshape(world, -1).copy()
+        slot["d_in"].copy_(slot["h_in"], non_blocking=True)
+        dist.all_gather_into_tensor(slot["d_out"], slot["d_in"], group=group)   # enqueued; the host does not wait for it
+        slot["h_out"].copy_(slot["d_out"], non_blocking=True)
+        slot["event"].record(ctx["stream"])
+    return PartialGather(slot=slot, event=slot["event"])
+
+
+def all_gather_partials(partial, device=None, group=None):
+    """partial: uint64[L] on the host -> uint64[world, L] (rank order) on every rank (start + wait)."""
+    return all_gather_partials_start(partial, device=device, group=group).result()
 
 
 def fold_partials(group_id, partials):
@@ -75,6 +105,21 @@ def fold_partials(group_id, partials):
 def sharded_msm(group_id, local_partial, device=None, group=None):
     """local_partial: this rank's XYZZ partial (uint64[16|32]) -> the global MSM result on every rank."""
     return fold_partials(group_id, all_gather_partials(local_partial, device=device, group=group))
+
+
+class ShardedMsmResult:
+    """Handle of a sharded MSM whose partial exchange is in flight (sharded_msm_start); .result() -> the global point."""
+
+    def __init__(self, group_id, gather):
+        self._group_id, self._gather = group_id, gather
+
+    def result(self):
+        return fold_partials(self._group_id, self._gather.result())
+
+
+def sharded_msm_start(group_id, local_partial, device=None, group=None):
+    """The pipelined form of sharded_msm: starts the exchange of this rank's partial and returns at once."""
+    return ShardedMsmResult(group_id, all_gather_partials_start(local_partial, device=device, group=group))
 
 
 # ------------------------------------------------------------------------------------------------
