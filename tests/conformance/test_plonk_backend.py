@@ -387,3 +387,80 @@ def test_e2e_public_inputs_cross_circuit_and_double_tampering(x3, add1):
     bad = copy.deepcopy(x3["proof"])
     bad.a_comm, bad.a_eval = ec_mul(G1, FR(424242)), bad.a_eval + FR(1)
     assert verify(bad, x3["pub"], x3["pp"], x3["srs"]) is False
+
+
+# ------------------------------------------------------------------ round-by-round resume through the wire format
+def test_prover_resumes_from_persisted_state_between_rounds(setup):
+    """The reference's web flow runs ONE round per request: it persists the round's outputs as JSON and rebuilds a fresh
+    ProverState from storage before the next round (plonk_routes.py:298-373, the checkpoint / resume of SURVEY.md section 5).
+    The same walk through zkhip.serializers -- every object JSON-encoded and decoded between rounds, a new ProverState each
+    time -- must end in the proof an uninterrupted run gives for the same blinding scalars, and that proof must survive its own
+    wire format and verify."""
+    import json
+    from zkhip import serializers as ser
+    circuit, a, b, c, pub, srs, pp = setup
+    blinding = [123456789 + 1000003 * k for k in range(9)]
+    want = prove(circuit, a, b, c, pub, pp, srs, blinding=blinding)
+
+    store = json.loads(json.dumps({                                           # what the routes keep in their database
+        "srs": ser.serialize_srs(srs), "pp": ser.serialize_preprocessed(pp),
+        "a": ser.serialize_fr_list(a), "b": ser.serialize_fr_list(b), "c": ser.serialize_fr_list(c), "pub": ser.serialize_fr_list(pub)}))
+
+    def rebuild(upto, left):
+        srs2, pp2 = ser.deserialize_srs(store["srs"]), ser.deserialize_preprocessed(store["pp"])
+        st = ProverState(ser.deserialize_fr_list(store["a"]), ser.deserialize_fr_list(store["b"]), ser.deserialize_fr_list(store["c"]),
+                         ser.deserialize_fr_list(store["pub"]), pp2, srs2, blinding=left)
+        if upto >= 2:
+            r1 = store["r1"]
+            st.a_poly, st.b_poly, st.c_poly, st.pi_poly = (ser.deserialize_poly(r1[k]) for k in ("a_poly", "b_poly", "c_poly", "pi_poly"))
+            st.proof.a_comm, st.proof.b_comm, st.proof.c_comm = (ser.deserialize_g1(r1[k]) for k in ("a_comm", "b_comm", "c_comm"))
+            st.transcript = ser.deserialize_transcript(r1["transcript"])
+        if upto >= 3:
+            r2 = store["r2"]
+            st.beta, st.gamma, st.z_poly = ser.deserialize_fr(r2["beta"]), ser.deserialize_fr(r2["gamma"]), ser.deserialize_poly(r2["z_poly"])
+            st.proof.z_comm = ser.deserialize_g1(r2["z_comm"])
+            st.transcript = ser.deserialize_transcript(r2["transcript"])
+        if upto >= 4:
+            r3 = store["r3"]
+            st.alpha = ser.deserialize_fr(r3["alpha"])
+            st.t_lo_poly, st.t_mid_poly, st.t_hi_poly = (ser.deserialize_poly(r3[k]) for k in ("t_lo_poly", "t_mid_poly", "t_hi_poly"))
+            st.proof.t_lo_comm, st.proof.t_mid_comm, st.proof.t_hi_comm = (ser.deserialize_g1(r3[k]) for k in ("t_lo_comm", "t_mid_comm", "t_hi_comm"))
+            st.transcript = ser.deserialize_transcript(r3["transcript"])
+        if upto >= 5:
+            r4 = store["r4"]
+            st.zeta = ser.deserialize_fr(r4["zeta"])
+            for k in ("a_eval", "b_eval", "c_eval", "s_sigma1_eval", "s_sigma2_eval", "z_omega_eval"):
+                setattr(st.proof, k, ser.deserialize_fr(r4[k]))
+            st.transcript = ser.deserialize_transcript(r4["transcript"])
+        return st
+
+    def persist(key, obj):
+        store[key] = json.loads(json.dumps(obj))
+
+    st = rebuild(1, blinding[:6])
+    round1.execute(st)
+    persist("r1", {**{k: ser.serialize_poly(getattr(st, k)) for k in ("a_poly", "b_poly", "c_poly", "pi_poly")},
+                   **{k: ser.serialize_g1(getattr(st.proof, k)) for k in ("a_comm", "b_comm", "c_comm")},
+                   "transcript": ser.serialize_transcript(st.transcript)})
+    st = rebuild(2, blinding[6:])
+    round2.execute(st)
+    persist("r2", {"beta": ser.serialize_fr(st.beta), "gamma": ser.serialize_fr(st.gamma), "z_poly": ser.serialize_poly(st.z_poly),
+                   "z_comm": ser.serialize_g1(st.proof.z_comm), "transcript": ser.serialize_transcript(st.transcript)})
+    st = rebuild(3, [])
+    round3.execute(st)
+    persist("r3", {"alpha": ser.serialize_fr(st.alpha), **{k: ser.serialize_poly(getattr(st, k)) for k in ("t_lo_poly", "t_mid_poly", "t_hi_poly")},
+                   **{k: ser.serialize_g1(getattr(st.proof, k)) for k in ("t_lo_comm", "t_mid_comm", "t_hi_comm")},
+                   "transcript": ser.serialize_transcript(st.transcript)})
+    st = rebuild(4, [])
+    round4.execute(st)
+    persist("r4", {"zeta": ser.serialize_fr(st.zeta), **{k: ser.serialize_fr(getattr(st.proof, k)) for k in
+                                                          ("a_eval", "b_eval", "c_eval", "s_sigma1_eval", "s_sigma2_eval", "z_omega_eval")},
+                   "transcript": ser.serialize_transcript(st.transcript)})
+    st = rebuild(5, [])
+    round5.execute(st)
+    got = st.build_proof()
+    for f in Proof.FIELDS:
+        assert getattr(got, f) == getattr(want, f), f
+    back = ser.deserialize_proof(json.loads(json.dumps(ser.serialize_proof(got))))
+    assert all(getattr(back, f) == getattr(want, f) for f in Proof.FIELDS)
+    assert verify(back, ser.deserialize_fr_list(store["pub"]), ser.deserialize_preprocessed(store["pp"]), ser.deserialize_srs(store["srs"])) is True
