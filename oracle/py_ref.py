@@ -25,7 +25,9 @@ vector.  This restatement is therefore pinned by (i) the F_r known-answers that 
 in reference comments (zkp/groth16/backend.py:355,363-367), (ii) the relational identities
 the reference's tests assert (tests/groth16/test_setup.py, tests/plonk/test_crypto.py:113-191,
 tests/plonk/test_foundation.py:486-540) and (iii) on-curve / group-order checks.
-EC coordinates are "parity unpinned" against the real py_ecc; see DESIGN.md.
+EC coordinates are "parity unpinned" against the real py_ecc; see DESIGN.md.  Second sources added in round 2
+(tests/test_oracle.py): SymPy's EllipticCurve for G1, SymPy's FiniteExtension arithmetic under the textbook formulas for
+G2 and for FQ12 products / inverses, the public constants 2*G1 (EIP-196) and omega_{2^28}.
 
 Representation: F_p / F_r elements are Python ints in [0, modulus); F_p^2 elements are
 2-tuples (c0, c1) = c0 + c1*i; G1 points are (x, y) int tuples; G2 points are

@@ -65,6 +65,169 @@ def test_public_curve_constants():
         assert o.get_root_of_unity(1 << log_n) == pow(w28, 1 << (28 - log_n), R)
 
 
+def _sympy_curve():
+    sympy = pytest.importorskip("sympy")
+    from sympy.ntheory.elliptic_curve import EllipticCurve
+    curve = EllipticCurve(0, 3, modulus=o.P)
+    return curve, curve(1, 2)
+
+
+def _sym_mul(gen, k):
+    q = (k % R) * gen
+    return (int(q.x), int(q.y))
+
+
+def test_g1_arithmetic_against_sympy():
+    """An implementation that is neither this repo's nor py_ecc's: SymPy's EllipticCurve over GF(p) (affine chord-and-tangent
+    with its own modular inverses).  Multiples of the generator, sums and a doubling from both oracles must equal SymPy's --
+    an independent pin of the G1 side (the reference's tests hold no EC coordinate; G2 and the pairing have no such
+    second source here)."""
+    curve, gen = _sympy_curve()
+    rng = random.Random(17)
+    ks = [1, 2, 3, 5, 35, R - 1, R - 2, (1 << 200) + 12345] + [rng.randrange(R) for _ in range(6)]
+    for k in ks:
+        want = _sym_mul(gen, k)
+        assert o.g1_multiply(o.G1, k) == want and co.g1_mul(o.G1, k) == want, k
+    a, b = rng.randrange(R), rng.randrange(R)
+    pa, pb = o.g1_multiply(o.G1, a), o.g1_multiply(o.G1, b)
+    s = curve(pa[0], pa[1]) + curve(pb[0], pb[1])
+    assert o.g1_add(pa, pb) == (int(s.x), int(s.y)) == co.g1_add(pa, pb)
+    d = curve(pa[0], pa[1]) + curve(pa[0], pa[1])
+    assert o.g1_double(pa) == (int(d.x), int(d.y))
+    assert o.g1_add(pa, o.g1_neg(pa)) is None
+
+
+def test_golden_g1_points_against_sympy(toy, kzg, golden_dir):
+    """Every G1 point of the committed fixtures that has a known discrete logarithm, recomputed with SymPy from that scalar:
+    the toy Groth16 proof (A, C) and CRS, the SRS of seed 42 and its KZG commitments, and the PLONK proofs' commitments
+    (= p(tau) * G1 for the polynomials stored next to them)."""
+    curve, gen = _sympy_curve()
+    pt = lambda v: (int(v[0]), int(v[1]))
+    t = toy["inputs"]
+    assert pt(toy["proof_A"]) == _sym_mul(gen, int(toy["A"])) and pt(toy["proof_C"]) == _sym_mul(gen, int(toy["C"]))
+    assert [pt(p) for p in toy["sigma1_1"]] == [_sym_mul(gen, t[k]) for k in ("alpha", "beta", "delta")]
+    assert [pt(p) for p in toy["sigma1_2"]] == [_sym_mul(gen, pow(t["x_val"], j, R)) for j in range(len(toy["sigma1_2"]))]
+    tau = int(kzg["tau"])
+    assert [pt(p) for p in kzg["g1_powers"]] == [_sym_mul(gen, pow(tau, j, R)) for j in range(len(kzg["g1_powers"]))]
+    for name, case in kzg["commits"].items():
+        scalar = o.horner([int(c) for c in case["coeffs"]], tau)
+        assert (None if case["commitment"] is None else pt(case["commitment"])) == (None if scalar == 0 else _sym_mul(gen, scalar)), name
+    with open(os.path.join(golden_dir, "plonk_proofs.json")) as f:
+        plonk = json.load(f)["cases"]
+    for name, case in plonk.items():
+        tau = o.srs_tau(case["srs"]["seed"])
+        for poly, comm in (("a_poly", "a_comm"), ("b_poly", "b_comm"), ("c_poly", "c_comm"), ("z_poly", "z_comm"), ("t_lo_poly", "t_lo_comm"),
+                           ("t_mid_poly", "t_mid_comm"), ("t_hi_poly", "t_hi_comm")):
+            scalar = o.horner([int(c) for c in case["polys"][poly]], tau)
+            assert pt(case["proof"][comm]) == _sym_mul(gen, scalar), (name, comm)
+
+
+class _SympyG2:
+    """The twist y^2 = x^3 + 3/(9+i) over F_p[i]/(i^2+1) with SymPy's FiniteExtension doing ALL field arithmetic (products,
+    the reduction by i^2 = -1, inversions); only the textbook chord-and-tangent formulas are written here.  A second source for
+    the oracle's F_p^2 arithmetic and G2 coordinates -- not as independent as SymPy's own EllipticCurve is for G1 (the three
+    formulas are restated), but none of the oracle's field code is involved."""
+
+    def __init__(self):
+        sympy = pytest.importorskip("sympy")
+        from sympy.polys.agca.extensions import FiniteExtension
+        self.i = sympy.symbols("i")
+        self.K = FiniteExtension(sympy.Poly(self.i ** 2 + 1, self.i, domain=sympy.GF(o.P, symmetric=False)))
+
+    def el(self, c):
+        return self.K.convert(int(c[0])) + self.K.convert(int(c[1])) * self.K.convert(self.i)
+
+    def pt(self, p):
+        return None if p is None else (self.el(p[0]), self.el(p[1]))
+
+    def coords(self, p):
+        if p is None:
+            return None
+        out = []
+        for e in p:
+            lst = [int(v) % o.P for v in e.rep.to_list()]
+            lst = [0] * (2 - len(lst)) + lst
+            out.append((lst[1], lst[0]))
+        return tuple(out)
+
+    def dbl(self, p):
+        x, y = p
+        lam = (self.K.convert(3) * x * x) / (self.K.convert(2) * y)
+        x3 = lam * lam - x - x
+        return (x3, lam * (x - x3) - y)
+
+    def add(self, p, q):
+        if p is None or q is None:
+            return q if p is None else p
+        if p[0] == q[0]:
+            return self.dbl(p) if p[1] == q[1] else None
+        lam = (q[1] - p[1]) / (q[0] - p[0])
+        x3 = lam * lam - p[0] - q[0]
+        return (x3, lam * (p[0] - x3) - p[1])
+
+    def mul(self, p, k):
+        r = None
+        for bit in bin(k % R)[2:]:
+            r = None if r is None else self.dbl(r)
+            if bit == "1":
+                r = self.add(r, p)
+        return r
+
+    def on_curve(self, p):
+        b2 = self.K.convert(3) / self.el((9, 1))
+        return p[1] * p[1] == p[0] * p[0] * p[0] + b2
+
+
+def test_g2_arithmetic_and_fixtures_against_sympy_extension_field(toy, kzg):
+    g2 = _SympyG2()
+    gen = g2.pt(o.G2)
+    assert g2.on_curve(gen)
+    rng = random.Random(23)
+    for k in [2, 3, 7, R - 1] + [rng.randrange(R) for _ in range(4)]:
+        want = g2.coords(g2.mul(gen, k))
+        assert o.g2_multiply(o.G2, k) == want and co.g2_mul(o.G2, k) == want, k
+    a, b = o.g2_multiply(o.G2, 1234567), o.g2_multiply(o.G2, 7654321)
+    assert o.g2_add(a, b) == g2.coords(g2.add(g2.pt(a), g2.pt(b))) and o.g2_double(a) == g2.coords(g2.dbl(g2.pt(a)))
+    assert g2.mul(gen, R) is None
+    # the G2 side of the committed fixtures
+    t = toy["inputs"]
+    assert [_g2(p) for p in toy["sigma2_1"]] == [g2.coords(g2.mul(gen, t[k])) for k in ("beta", "gamma", "delta")]
+    assert [_g2(p) for p in toy["sigma2_2"]] == [g2.coords(g2.mul(gen, pow(t["x_val"], j, R))) for j in range(len(toy["sigma2_2"]))]
+    assert _g2(toy["proof_B"]) == g2.coords(g2.mul(gen, int(toy["B"])))
+    assert [_g2(p) for p in kzg["g2_powers"]] == [o.G2, g2.coords(g2.mul(gen, int(kzg["tau"])))]
+
+
+def test_fq12_arithmetic_against_sympy_extension_field():
+    """py_ecc's FQ12 = F_p[w] / (w^12 - 18 w^6 + 82) (bn128 FQ12_MODULUS_COEFFS): products and inverses of the oracle's
+    coefficient-list arithmetic against SymPy's FiniteExtension over the same modulus, and the embedding of F_p^2
+    (i = w^6 - 9) that the twist uses."""
+    sympy = pytest.importorskip("sympy")
+    from sympy.polys.agca.extensions import FiniteExtension
+    w = sympy.symbols("w")
+    K = FiniteExtension(sympy.Poly(w ** 12 - 18 * w ** 6 + 82, w, domain=sympy.GF(o.P, symmetric=False)))
+    gen = K.convert(w)
+
+    def el(coeffs):
+        acc, pw = K.convert(0), K.convert(1)
+        for c in coeffs:
+            acc = acc + K.convert(int(c)) * pw
+            pw = pw * gen
+        return acc
+
+    def coeffs(e):
+        lst = [int(v) % o.P for v in e.rep.to_list()]
+        return ([0] * (12 - len(lst)) + lst)[::-1]
+
+    rng = random.Random(29)
+    for _ in range(3):
+        a = [rng.randrange(o.P) for _ in range(12)]
+        b = [rng.randrange(o.P) for _ in range(12)]
+        assert [int(v) for v in o.f12_mul(a, b)] == coeffs(el(a) * el(b))
+        assert [int(v) for v in o.f12_inv(a)] == coeffs(K.convert(1) / el(a))
+    i_embedded = [(-9) % o.P] + [0] * 5 + [1] + [0] * 5                       # i = w^6 - 9
+    assert [int(v) for v in o.f12_mul(i_embedded, i_embedded)] == [o.P - 1] + [0] * 11   # i^2 = -1
+
+
 def test_reference_comment_kats():
     """F_r known-answers that survive in zkp/groth16/backend.py:355,363 (with pub = [0, 1])."""
     d = o.toy_groth16()
