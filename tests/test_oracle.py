@@ -228,6 +228,27 @@ def test_fq12_arithmetic_against_sympy_extension_field():
     assert [int(v) for v in o.f12_mul(i_embedded, i_embedded)] == [o.P - 1] + [0] * 11   # i^2 = -1
 
 
+def test_ntt_against_sympy(ntt):
+    """sympy.discrete.transforms.ntt(seq, prime=r) picks the smallest primitive root of r -- 5, the reference's generator
+    (zkp/plonk/field.py:178-180) -- and returns natural order: the same transform as fft(coeffs, get_root_of_unity(n)).
+    Both oracles and the committed NTT fixture against it, forward and inverse."""
+    sympy = pytest.importorskip("sympy")
+    from sympy.discrete.transforms import intt as sym_intt, ntt as sym_ntt
+    assert sympy.ntheory.primitive_root(R) == 5
+    rng = random.Random(31)
+    for n in (1, 2, 8, 64, 1024):
+        seq = [rng.randrange(R) for _ in range(n)]
+        want = [int(v) for v in sym_ntt(seq, prime=R)]
+        w = o.get_root_of_unity(n)
+        assert o.fft(seq, w) == want
+        assert co.from_limbs(co.ntt_arr(co.to_limbs(seq), w)) == want
+        assert o.ifft(want, w) == seq == [int(v) for v in sym_intt(want, prime=R)]
+    for name, case in ntt["cases"].items():
+        coeffs = [int(c) for c in case["coeffs"]]
+        assert [int(v) for v in case["fft"]] == [int(v) for v in sym_ntt(coeffs, prime=R)], name
+        assert [int(v) for v in case["ifft_of_coeffs"]] == [int(v) for v in sym_intt(coeffs, prime=R)], name
+
+
 def test_reference_comment_kats():
     """F_r known-answers that survive in zkp/groth16/backend.py:355,363 (with pub = [0, 1])."""
     d = o.toy_groth16()
