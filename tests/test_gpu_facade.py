@@ -279,6 +279,36 @@ def test_public_curve_constants_through_the_backend():
     assert [int(v) for v in ev] == [pow(w28, (1 << 24) * i, CURVE_ORDER) for i in range(n)]
 
 
+def test_backend_against_sympy_directly():
+    """The GPU backend against a third-party implementation with no oracle in between: G1 scalar multiplications, an MSM and a
+    commitment against SymPy's EllipticCurve over GF(p); fft / ifft against sympy.discrete.transforms.ntt / intt (primitive
+    root 5, natural order -- the reference's convention)."""
+    import random
+    sympy = pytest.importorskip("sympy")
+    from sympy.discrete.transforms import intt as sym_intt, ntt as sym_ntt
+    from sympy.ntheory.elliptic_curve import EllipticCurve
+    from zkhip.field import FIELD_MODULUS, msm_g1
+    curve = EllipticCurve(0, 3, modulus=FIELD_MODULUS)
+    gen = curve(1, 2)
+    sym = lambda k: (lambda q: (FQ(int(q.x)), FQ(int(q.y))))((k % CURVE_ORDER) * gen)
+    rng = random.Random(41)
+    ks = [rng.randrange(CURVE_ORDER) for _ in range(6)]
+    pts = [ec_mul(G1, k) for k in ks]
+    assert pts == [sym(k) for k in ks]
+    ss = [rng.randrange(CURVE_ORDER) for _ in range(6)]
+    assert msm_g1([FR(v) for v in ss], pts) == sym(sum(a * b for a, b in zip(ss, ks)))
+    srs = SRS.generate(max_degree=5, seed=42)
+    tau = int.from_bytes(__import__("hashlib").sha256(b"42").digest(), "big") % CURVE_ORDER          # zkp/plonk/srs.py:68-70
+    coeffs = [rng.randrange(CURVE_ORDER) for _ in range(6)]
+    assert commit(Polynomial(coeffs), srs) == sym(sum(c * pow(tau, j, CURVE_ORDER) for j, c in enumerate(coeffs)))
+    for n in (8, 64, 1024):
+        seq = [rng.randrange(CURVE_ORDER) for _ in range(n)]
+        w = get_root_of_unity(n)
+        want = [int(v) for v in sym_ntt(seq, prime=CURVE_ORDER)]
+        assert [int(v) for v in fft(seq, w)] == want
+        assert [int(v) for v in ifft(want, w)] == seq == [int(v) for v in sym_intt(want, prime=CURVE_ORDER)]
+
+
 def test_verifiers_refuse_off_curve_proof_points(pipeline, srs_small):
     """py_ecc's pairing asserts is_on_curve for both arguments, so the reference's verifiers raise on a proof element that
     is not a curve point; the backend refuses the same inputs (AssertionError from the facade, ZK_ERR_INVALID at the ABI)
