@@ -39,8 +39,8 @@ G1_BYTES_PER_POINT = 96  # 32 B scalar + 64 B affine point, each read once (SURV
 MADS_PER_MADD = 1467     # v_mad_u64_u32 in one XYZZ += affine addition as compiled (code object of msm_accumulate_kernel<Fp>)
 
 
-from zkhip.synthetic import (R_MOD, arithmetic_dot, arithmetic_dot_device, arithmetic_points, fixed_base_points,  # noqa: E402
-                             limbs_dot_mod_r, random_scalars, random_scalars_device)
+from zkhip.synthetic import (R_MOD, arithmetic_dot_device, arithmetic_points, limbs_dot_mod_r, random_scalars,  # noqa: E402
+                             random_scalars_device)
 
 
 def _free_port():
@@ -268,7 +268,7 @@ def main():
             ok_all = torch.ones(1, device=cdev)
         except Exception as exc:                                              # noqa: BLE001 -- keep the ranks in step
             ok_all = torch.zeros(1, device=cdev)
-            shard_err = repr(exc)
+            sys.stderr.write("sharded_one_msm set-up failed on rank %d: %r\n" % (rank, exc))
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
         if float(ok_all.item()) == 1.0:
             one = lambda: sharded_msm(_lib.GROUP_G1, plan2.run_partial(d_s2.data_ptr(), d_p2.data_ptr(), m_loc, stream), device=cdev)

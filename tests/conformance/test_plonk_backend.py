@@ -10,7 +10,7 @@ import random
 
 import pytest
 
-from zkhip.field import CURVE_ORDER, FQ, FQ12, FR, G1, G2, Z1, ec_add, ec_mul, ec_neg, ec_pairing, get_root_of_unity, get_roots_of_unity
+from zkhip.field import CURVE_ORDER, FQ, FQ12, FR, G1, G2, Z1, ec_add, ec_mul, ec_neg, ec_pairing, get_root_of_unity
 from zkhip.plonk.circuit import Circuit
 from zkhip.plonk.kzg import commit, create_witness, verify_opening
 from zkhip.plonk.permutation import K1, K2

@@ -224,7 +224,7 @@ def test_g1_msm_2pow16_bit_exact():
 def test_g1_msm_skewed_scalars_large(pattern):
     """Hot digits at 2^18 points: cells far larger than one workgroup's share and buckets with up to n entries
     (multi-workgroup cell sort, heavy-bucket wavefront tasks) -- bit-exact against the oracle's serial bucket MSM."""
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     rng = np.random.default_rng(4242)
     n = (1 << 18) + 77
     K = random_scalars(rng, n)
@@ -249,7 +249,7 @@ def test_g1_msm_skewed_scalars_large(pattern):
 @pytest.mark.parametrize("n", [131072, 131073, 300001])
 def test_g1_msm_closed_form_across_c16_switch(n):
     """P_i = k_i*G1 (generated on the GPU, spot-checked against the oracle): MSM = (sum s_i k_i) * G1."""
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     rng = np.random.default_rng(n)
     S, K = random_scalars(rng, n), random_scalars(rng, n)
     g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
@@ -263,7 +263,7 @@ def test_g1_msm_closed_form_across_c16_switch(n):
 def test_g1_msm_2pow20_closed_form_and_linearity():
     """BASELINE.json configs[1] size.  P_i = k_i*G1, so MSM(s, P) = (sum s_i k_i mod r) * G1; also
     MSM(2s) = 2*MSM(s) and MSM(s) + MSM(t) = MSM(s + t)."""
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     rng = np.random.default_rng(14)
     n = 1 << 20
     S, T, K = random_scalars(rng, n), random_scalars(rng, n), random_scalars(rng, n)
@@ -291,7 +291,7 @@ def test_g1_msm_2pow20_closed_form_and_linearity():
 def test_g1_msm_2pow20_bit_exact_vs_oracle_pippenger():
     """BASELINE.json configs[1] in full: 2^20 random scalars x points, the GPU result against the oracle's serial
     bucket-method MSM (a structurally different restatement: unsigned windows, Jacobian, running sums) -- bit-exact."""
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     rng = np.random.default_rng(2020)
     n = 1 << 20
     S, K = random_scalars(rng, n), random_scalars(rng, n)
@@ -367,7 +367,7 @@ def test_g1_msm_2pow24_chunked_closed_form():
     """BASELINE.json's 2^24 size on one GPU: four 2^22-point chunks through the plan's lanes; P_i = (k0 + i d) G so that the
     result has the closed form (sum s_i (k0 + i d)) G; a few bases are spot-checked against the oracle."""
     import torch
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     from helpers import arithmetic_dot, arithmetic_g1_points
     n = 1 << 24
     k0, d = 0x1234567890ABCDEF >> 1, 0x9E3779B1
@@ -436,7 +436,7 @@ def test_bound_bases_mode_equals_unbound(group, chunk_log):
         from helpers import arithmetic_g1_points
         Pts = arithmetic_g1_points(_lib.load(), n, 0x1234567890ABCDEF >> 1, 0x9E3779B1)
     Pts[7] = 0                                                        # an infinity base
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     S = random_scalars(rng, n)
     S[3] = 0
     S[4] = limb_row(o.R - 1)
@@ -480,7 +480,7 @@ def test_g1_top_window_spreading_edges():
     table row would otherwise use a fraction of its buckets).  The values around the 2^240 threshold and just below r sit
     at odd and even positions here; both modes must give the closed form (sum s_i k_i) * G1."""
     import torch
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     from helpers import arithmetic_dot, arithmetic_g1_points
     n = (1 << 17) + 4097
     k0, d = 0x0123456789ABCDE, 0x9E3779B1

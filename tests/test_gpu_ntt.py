@@ -39,7 +39,7 @@ def test_ntt_bit_exact_vs_oracle(L):
 
 
 def _fast_rand(rng, n):
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     return random_scalars(rng, n)
 
 

@@ -22,7 +22,7 @@ from zkhip.field import FQ, FR, g1_to_limbs
 from zkhip.plonk.circuit import Circuit, Gate
 from zkhip.plonk.permutation import build_permutation_polynomials
 from zkhip.plonk.preprocessor import preprocess
-from zkhip.plonk.prover import Proof, ProverState, prove, round1, round2, round3, round4, round5
+from zkhip.plonk.prover import ProverState, prove, round1, round2, round3, round4, round5
 from zkhip.plonk.prover_device import DevicePlonk
 from zkhip.plonk.srs import SRS
 from zkhip.plonk.verifier import verify

@@ -16,7 +16,7 @@ def main():
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     from zkhip.distributed import DistNtt
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

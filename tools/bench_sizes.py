@@ -6,7 +6,7 @@ import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
-from bench import random_scalars, limbs_dot_mod_r, R_MOD
+from zkhip.synthetic import random_scalars, limbs_dot_mod_r, R_MOD
 
 
 from zkhip.synthetic import arithmetic_dot, arithmetic_points  # noqa: E402

@@ -28,7 +28,7 @@ def main():
     import time
 
     import torch
-    from bench import random_scalars
+    from zkhip.synthetic import random_scalars
     from zkhip import _lib
     from zkhip.device import MsmPlan
 

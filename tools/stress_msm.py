@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--max-log", type=int, default=19)
     a = ap.parse_args()
     import torch
-    from bench import random_scalars, limbs_dot_mod_r, R_MOD
+    from zkhip.synthetic import random_scalars, limbs_dot_mod_r, R_MOD
     from zkhip import _lib
     from zkhip.device import MsmPlan
     from zkhip.field import G1, G2, ec_mul, g2_to_limbs, limbs_to_g1, limbs_to_g2
