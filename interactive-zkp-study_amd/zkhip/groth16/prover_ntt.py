@@ -21,7 +21,7 @@ size is checked against closed-form scalars computed from the known toxic waste
 import numpy as np
 
 from .. import _lib
-from ..device import MsmPlan, NttPlan, fr_quotient
+from ..device import FrVec, MsmPlan, NttPlan, fr_quotient
 from ..field import CURVE_ORDER as R, G1, G2, fixed_base_mul, g1_to_limbs, g2_to_limbs, msm_g1, limbs_to_g1
 
 COSET_SHIFT = 5  # the reference's coset generator (zkp/plonk/utils.py:166-167)
@@ -167,12 +167,13 @@ class ScaleProver:
         c = crs.circuit
         self.m, self.W = c.m, c.num_wires
         self.ntt = NttPlan(c.log_m)
-        self.g1 = MsmPlan(_lib.GROUP_G1, max(self.W, self.m + 3))
-        self.g2 = MsmPlan(_lib.GROUP_G2, self.m + 2)
         # The CRS never changes: bind the three G1 queries as one array (sigma1_2+ | sigma1_4 | sigma1_5) and sigma2_2+ in G2:
         # tables of 2^(20 w) * P, 13 n bucket additions per MSM instead of 16 n (zk_msm_plan_bind_points).
         self.bound = self.m + 2 > (1 << 17)
         self.off14, self.off15 = self.m + 3, self.m + 3 + self.W
+        self.n_c = self.off15 + self.m - 1                     # all three queries behind each other: (m+3) + W + (m-1) bases
+        self.g1 = MsmPlan(_lib.GROUP_G1, self.n_c if self.bound else max(self.W, self.m + 3))
+        self.g2 = MsmPlan(_lib.GROUP_G2, self.m + 2)
         if self.bound:
             st0 = torch.cuda.current_stream().cuda_stream
             all_g1 = torch.cat([crs.d_s12, crs.d_s14, crs.d_s15])
@@ -182,6 +183,10 @@ class ScaleProver:
         new = lambda rows: torch.empty((rows, 4), dtype=torch.int64, device="cuda")
         self.ext_a, self.ext_b1, self.ext_b2 = new(self.m + 3), new(self.m + 3), new(self.m + 2)
         self.scratch = [new(self.m) for _ in range(4)]
+        # bound CRS: proof_C needs r*(beta + B(x)) + L + H only as a SUM, so the three queries run as ONE MSM over the whole bound
+        # array with the scalars (r*u_B | 0 0 r | w | h) behind each other -- the same bucket additions, one sort and one bucket
+        # reduction instead of three.  h (m coefficients, the last one zero) is computed in place at the tail of that buffer.
+        self.sc_c = new(self.n_c + 1) if self.bound else None
         self.zinv = pow((pow(COSET_SHIFT, self.m, R) - 1) % R, -1, R)  # 1 / Z_H on the coset k*H
 
     def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
@@ -198,6 +203,8 @@ class ScaleProver:
         m, W, crs = self.m, self.W, self.crs
         r, s = r % R, s % R
         ca, cb, cc, h = self.scratch
+        if self.bound:
+            h = self.sc_c[self.off15:self.off15 + m]           # the H coefficients land where the merged MSM reads them
         ua, ub = self.ext_a[:m], self.ext_b1[:m]
         ua.copy_(d_a)
         ub.copy_(d_b)
@@ -219,10 +226,22 @@ class ScaleProver:
             self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
-        # five MSMs, each in its own workspace and stream (the G1 plan keeps three in flight).  The G2 one leads: its long,
+        # The MSMs, each in its own workspace and stream (the G1 plan keeps three in flight).  The G2 one leads: its long,
         # latency-bound bucket reduction then runs beside the G1 accumulate kernels instead of alone.
         t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
         t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
+        if self.bound:
+            sc = self.sc_c
+            FrVec.lincomb(sc.data_ptr(), [ub.data_ptr()], [r], m, stream=st)             # r * u_B
+            sc[m:m + 3] = _dev(_lib.ints_to_limbs([0, 0, r]))                            # r * beta
+            sc[self.off14:self.off15].copy_(d_w)                                         # placeholders at public wires are infinity
+            t_c = self.g1.submit_bound(sc.data_ptr(), 0, self.n_c, st)                   # r*(beta + B(x)) + L + H
+            proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                      # proving.py:23-33
+            msm_c = self._pt(self.g1, self.g1.collect_limbs(t_c))
+            proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                     # proving.py:35-45
+            # proving.py:47-75 with the +-r*s*delta terms cancelled:  s*A + [r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H]
+            proof_c = msm_g1([s, 1], [proof_a, msm_c])
+            return proof_a, proof_b, proof_c, h
         t_b1 = self._msm(self.g1, self.ext_b1, crs.d_s12, 0, m + 3, st)                  # beta + B(x) in G1
         t_h = self._msm(self.g1, h, crs.d_s15, self.off15, m - 1, st)
         proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                          # proving.py:23-33

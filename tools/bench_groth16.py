@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Groth16 prove() wall-clock on a synthetic 2^log_m-constraint R1CS (BASELINE.json configs[3]):
-witness resident in HBM -> proof (A, B, C): sparse mat-vecs A.w, B.w, C.w, 7 NTTs, 4 G1 + 1 G2 MSMs; CRS and R1CS resident on the device.
+witness resident in HBM -> proof (A, B, C): sparse mat-vecs A.w, B.w, C.w, 7 NTTs, 2 G1 + 1 G2 MSMs (the three G1 queries behind proof_C run as
+one MSM over the bound CRS); CRS and R1CS resident on the device.
     python tools/bench_groth16.py --log-m 20 --reps 3
 Prints one JSON line with the timing breakdown; the proof is checked against the closed-form
 scalars the known toxic waste gives."""
