@@ -18,12 +18,14 @@ def main():
     ap.add_argument("--g2", default="")
     ap.add_argument("--ntt", default="16,18,20,22,24")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--chunk-log", type=int, default=0, help="chunk size of MSMs beyond it (zk_test_set_msm_chunk_log; 0 = the library's 2^22)")
     args = ap.parse_args()
     import torch
     from zkhip import _lib
     from zkhip.device import MsmPlan, NttPlan
     from zkhip.field import G1, G2, ec_mul, limbs_to_g1, limbs_to_g2, g2_to_limbs
     lib = _lib.load()
+    _lib.check(lib.zk_test_set_msm_chunk_log(args.chunk_log))
     st = torch.cuda.current_stream().cuda_stream
     out = {"msm_g1": [], "msm_g2": [], "ntt": []}
     for group, sizes in (("g1", args.msm), ("g2", args.g2)):
