@@ -3,17 +3,17 @@
 // Replaces fft / ifft (zkp/plonk/polynomial.py:292-378) and coset_fft / coset_ifft
 // (zkp/plonk/utils.py:145-205).  n = 2^L is factored into D = ceil(L/8) digits n_1..n_D
 // (multi-step / Stockham-style autosort): pass p transforms digit p of every element inside an
-// LDS tile of 2^(l_p) x 2^g elements (2^g >= 8 adjacent elements per digit value keep every HBM
-// access a >= 256-byte run), multiplies by the inter-pass twiddle w_n^(k_p * rem) (two-level
+// LDS tile of 2^(l_p) x 2^g = 2^10 elements (2^g >= 4 adjacent elements per digit value keep every HBM
+// access a >= 128-byte run), multiplies by the inter-pass twiddle w_n^(k_p * rem) (two-level
 // table) and writes back; the last pass transforms the contiguous digit and writes to the
 // digit-reversed position, which makes the output natural-order with no separate bit-reversal
-// pass.  Inside a tile the decimation-in-frequency butterflies run three stages at a time on 8
-// elements held in registers (one LDS round trip per three stages).  Element VALUES are never
+// pass.  Inside a tile the decimation-in-frequency butterflies run two stages at a time on 4
+// elements held in registers (one LDS round trip per two stages; three workgroups per CU).  Element VALUES are never
 // converted to Montgomery form: only the twiddles are (mont_mul(x, w*R) = x*w); elements are
 // kept as lazy 9x29-bit limbs (< 2r) in LDS and in the scratch buffer between passes, and are
 // canonical 32-byte words only at the first load and the last store.
-// HBM traffic: 64..72 bytes per element per pass; the kernel is bound by the ~15 modular
-// products per element (butterflies + 2 per pass boundary), not by bandwidth.
+// HBM traffic: 64..72 bytes per element per pass; the kernel is bound by the vector-ALU issue rate (~10.5 modular
+// products per element: butterflies + one per pass boundary, and 22 modular additions / subtractions), not by bandwidth.
 #include <string.h>
 #include "common.h"
 #include "ntt.h"
@@ -21,7 +21,7 @@
 namespace zk {
 
 constexpr int NTT_NT = 256;  // threads per workgroup
-constexpr int NTT_G = 3;     // log2 adjacent elements per digit value
+constexpr int NTT_G = 2;     // log2 adjacent elements per digit value
 
 __device__ __forceinline__ Fr lds_ld(const uint32_t *base, uint32_t stride, uint32_t slot) {
     Fr r;
@@ -67,6 +67,11 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
 // and those butterflies skip the multiplication (all of stage 0, half of stage 1, a quarter of stage 2).
 // (Leaving the sums unreduced until the end of a round -- 7 conditional subtractions per 8 elements instead of 12 --
 // was tried: it needs 288 registers, and at one wavefront per SIMD the pass is 30 % slower; capped at 256 it spills.)
+// The pass kernel uses R = 2 (and R = 1 to finish an odd digit): three stages on 8 elements need 255 registers and a
+// 2^11-element tile to keep 256 threads busy -- two workgroups per CU, two wavefronts per SIMD, 72 % of the vector-ALU issue
+// rate (profiles/r02_pmc_sq_summary.csv); two stages on 4 elements need 143 registers and a 2^10-element tile: three wavefronts
+// per SIMD, and although LDS is crossed four times per 8-bit digit instead of three a 2^22-point transform takes 0.57 ms
+// instead of 0.63 (2^24: 2.17 instead of 2.35 ms).
 template <int R, bool LAST>
 __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, uint32_t tile, uint32_t ntw, uint32_t lp, uint32_t g,
                                           int s_hi) {
@@ -155,16 +160,12 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     }
     __syncthreads();
 
-    // decimation-in-frequency butterflies over the digit index j (slot = j * G + c), up to three
-    // stages per LDS round trip (radix-8 / radix-4 in registers)
+    // decimation-in-frequency butterflies over the digit index j (slot = j * G + c), two stages per LDS round trip (radix-4 in
+    // registers: four elements per thread and round, see the plan's tile size)
     for (int sh = (int)lp - 1; sh >= 0;) {
-        const int rem = sh + 1;
-        const int R = (rem >= 5 || rem == 3) ? 3 : (rem == 1 ? 1 : 2);
+        const int R = sh == 0 ? 1 : 2;
         const bool last = (sh - R + 1 == 0);
-        if (R == 3) {
-            if (last) ntt_round<3, true>(data, tw, tile, ntw, lp, g, sh);
-            else ntt_round<3, false>(data, tw, tile, ntw, lp, g, sh);
-        } else if (R == 2) {
+        if (R == 2) {
             if (last) ntt_round<2, true>(data, tw, tile, ntw, lp, g, sh);
             else ntt_round<2, false>(data, tw, tile, ntw, lp, g, sh);
         } else {
@@ -295,6 +296,14 @@ NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     } else {
         const unsigned D = (L_ + 7) / 8;
         for (unsigned p = 0; p < D; p++) digits_.push_back(L_ / D + (p < L_ % D ? 1 : 0));
+        // the butterflies run two stages per LDS round trip: an odd digit ends on a single-stage round, so odd digits are paired off
+        // (2^22: 8 + 7 + 7 -> 8 + 8 + 6, eleven rounds instead of twelve)
+        for (unsigned i = 0; i < D; i++)
+            for (unsigned j = D; j-- > i + 1;)
+                if ((digits_[i] & 1) && digits_[i] < 8 && (digits_[j] & 1) && digits_[j] > 1) {
+                    digits_[i]++;
+                    digits_[j]--;
+                }
     }
     lmax_ = 0;
     for (uint32_t d : digits_) lmax_ = std::max(lmax_, d);
@@ -387,8 +396,8 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
             P.L = L_; P.lp = lp; P.sp = sp; P.lh = lh_;
             P.tw_shift = lmax_ - lp;
             const bool final_pass = (p == D - 1);
-            // tiles of up to 2^11 elements (every thread owns 8), but never fewer than ~512 tiles per pass
-            P.g = (D == 1) ? 0 : (uint32_t)std::max<int>(NTT_G, std::min<int>(11 - (int)lp, (int)L_ - (int)lp - 9));
+            // tiles of up to 2^10 elements (every thread owns 4; 41 KB of LDS: three workgroups per CU), but never fewer than ~512 tiles per pass
+            P.g = (D == 1) ? 0 : (uint32_t)std::max<int>(NTT_G, std::min<int>(10 - (int)lp, (int)L_ - (int)lp - 9));
             const void *src = (p == 0) ? static_cast<const void *>(data) : tmp_.p;
             void *dst = final_pass ? static_cast<void *>(data) : tmp_.p;
             const uint32_t tile = 1u << (lp + P.g);

@@ -9,6 +9,7 @@ counter passes (`--pmc`) separate from the kernel trace, one counter per pass.""
 import argparse, csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SQ_COUNTERS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"]
 BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--sizes", "", "--sizes-ntt", ""]
 
 
@@ -35,7 +36,33 @@ def run(rnd):
                 os.path.join(out, "pmc_%s.log" % ctr))
         if rc:
             return rc
-    return 0
+    # issue-slot accounting of the shader engines (one pass: 7 SQ counters + GRBM_GUI_ACTIVE)
+    return sh(["rocprofv3", "--pmc"] + SQ_COUNTERS + ["--output-format", "csv", "-d", os.path.join(out, "pmc_SQ"), "--"] + BENCH_QUICK + ["--steps", "3", "--warmup", "1"],
+              os.path.join(out, "pmc_SQ.log"))
+
+
+def fold_sq(src, dst, rnd):
+    """profiles/<round>_pmc_sq_summary.csv: per kernel, the SQ counters averaged over its dispatches and what they say about
+    the vector ALU.  SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles summed over all wavefronts (MI355X_MICROARCH.md),
+    SQ_INSTS_VALU counts wavefront-instructions, GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    found = sorted(glob.glob(os.path.join(src, "pmc_SQ", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not found:
+        return
+    acc = {}
+    for r in csv.DictReader(open(found[-1])):
+        k = short_name(r["Kernel_Name"])
+        d = acc.setdefault(k, {}).setdefault(r["Dispatch_Id"], {})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    with open(os.path.join(dst, rnd + "_pmc_sq_summary.csv"), "w") as f:
+        f.write("kernel,dispatches," + ",".join(SQ_COUNTERS) + ",valu_insts_per_simd_cycle,active_valu_frac_of_wave_cycles,wait_inst_frac_of_wave_cycles\n")
+        for k, disp in sorted(acc.items(), key=lambda kv: -sum(d.get("SQ_BUSY_CYCLES", 0) for d in kv[1].values())):
+            n = len(disp)
+            avg = {c: sum(d.get(c, 0.0) for d in disp.values()) / n for c in SQ_COUNTERS}
+            cyc = avg["GRBM_GUI_ACTIVE"] / 8.0                       # shader-clock cycles the dispatch was resident
+            simd_cyc = cyc * 256 * 4
+            per = avg["SQ_INSTS_VALU"] / simd_cyc if simd_cyc else 0.0
+            wc = avg["SQ_WAVE_CYCLES"] or 1.0
+            f.write('"%s",%d,%s,%.4f,%.4f,%.4f\n' % (k, n, ",".join("%.0f" % avg[c] for c in SQ_COUNTERS), per, avg["SQ_ACTIVE_INST_VALU"] / wc, avg["SQ_WAIT_INST_ANY"] / wc))
 
 
 def short_name(full):
@@ -95,6 +122,7 @@ def fold(rnd):
                             "raw reading, no x2 FETCH correction (64-byte gathers, not a 16 B/lane streaming read)" % rnd}
         with open(os.path.join(dst, "traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
+    fold_sq(src, dst, rnd)
     print("folded", src, "->", dst)
     return 0
 
