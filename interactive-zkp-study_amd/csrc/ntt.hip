@@ -33,6 +33,16 @@ __device__ __forceinline__ void lds_st(uint32_t *base, uint32_t stride, uint32_t
 #pragma unroll
     for (int i = 0; i < NL; i++) base[i * stride + slot] = v.l[i];
 }
+// Bank swizzle of a tile slot (dword index inside one limb plane).  ds_read_b32 / ds_write_b32 see 32 banks and resolve conflicts
+// per 32-lane half (MI355X_MICROARCH.md, LDS); the butterfly rounds address slots  hi << (s + 2 + g) | k << (s + g) | low << g | c,
+// the last pass stores its tile transposed (slot = j << g | c with j along the lanes), and with plain slots the late rounds are 2- to
+// 4-way and the transposed store 16-way conflicts (SQ_LDS_BANK_CONFLICT: 57-65 % of the LDS cycles of a pass).  XOR-ing slot bits
+// 5..8 into the bank bits -- b5 -> B2, b6 -> B3 and B4, b7 -> B0, b8 -> B1 -- makes every one of those patterns (and every aligned
+// run of 32 slots) conflict-free.  The map is linear over XOR: swz(a ^ b) = swz(a) ^ swz(b).
+__device__ __forceinline__ uint32_t swz(uint32_t slot) {
+    const uint32_t u = slot >> 5;
+    return slot ^ (((u & 3u) << 2) | ((u & 2u) << 3) | ((u >> 2) & 3u));
+}
 // canonical element (8 words, 32 B) <-> lazy limbs
 __device__ __forceinline__ Fr ld_canon(const uint32_t *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
@@ -69,21 +79,25 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
 // was tried: it needs 288 registers, and at one wavefront per SIMD the pass is 30 % slower; capped at 256 it spills.)
 // The pass kernel uses R = 2 (and R = 1 to finish an odd digit): three stages on 8 elements need 255 registers and a
 // 2^11-element tile to keep 256 threads busy -- two workgroups per CU, two wavefronts per SIMD, 72 % of the vector-ALU issue
-// rate (profiles/r02_pmc_sq_summary.csv); two stages on 4 elements need 143 registers and a 2^10-element tile: three wavefronts
-// per SIMD, and although LDS is crossed four times per 8-bit digit instead of three a 2^22-point transform takes 0.57 ms
-// instead of 0.63 (2^24: 2.17 instead of 2.35 ms).
+// rate; two stages on 4 elements need 144 registers and a 2^10-element tile: three wavefronts per SIMD, 79 % of the issue
+// rate (profiles/r02_pmc_sq_summary.csv), and although LDS is crossed four times per 8-bit digit instead of three a 2^22-point
+// transform takes 0.51 ms instead of 0.545 (both libraries on one box, a hundred round trips; 2^20: 0.147 instead of 0.155).
 template <int R, bool LAST>
 __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, uint32_t tile, uint32_t ntw, uint32_t lp, uint32_t g,
                                           int s_hi) {
     const int s_lo = LAST ? 0 : s_hi - R + 1;
     const uint32_t ngroups = tile >> R;
+    uint32_t kx[1 << R];   // swizzle of the element bits k << (s_lo + g): uniform over the wavefront
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) kx[k] = swz((uint32_t)k << (s_lo + g));
     for (uint32_t gi = threadIdx.x; gi < ngroups; gi += NTT_NT) {
         const uint32_t c = gi & ((1u << g) - 1u), rest = gi >> g;
         const uint32_t low = rest & ((1u << s_lo) - 1u);
         const uint32_t jb = ((rest >> s_lo) << (s_hi + 1)) | low;
+        const uint32_t sb = swz((jb << g) | c);
         Fr x[1 << R];
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) x[k] = lds_ld(data, tile, ((jb | ((uint32_t)k << s_lo)) << g) | c);
+        for (int k = 0; k < (1 << R); k++) x[k] = lds_ld(data, tile, sb ^ kx[k]);
 #pragma unroll
         for (int b = R - 1; b >= 0; b--) {
             const int s = s_lo + b;
@@ -91,7 +105,7 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
             for (int q = 0; q < (1 << b); q++) {
                 const bool unit = LAST && q == 0;
                 Fr w;
-                if (!unit) w = lds_ld(tw, ntw, (low | ((uint32_t)q << s_lo)) << (lp - 1 - s));
+                if (!unit) w = lds_ld(tw, ntw, (1u << s) + (low | ((uint32_t)q << s_lo)));   // stage s: w^(j << (lp - 1 - s)) at 2^s + j
 #pragma unroll
                 for (int hi = 0; hi < (1 << (R - 1 - b)); hi++) {
                     const int k0 = (hi << (b + 1)) | q, k1 = k0 | (1 << b);
@@ -110,13 +124,15 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
             }
         }
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) lds_st(data, tile, ((jb | ((uint32_t)k << s_lo)) << g) | c, x[k]);
+        for (int k = 0; k < (1 << R); k++) lds_st(data, tile, sb ^ kx[k], x[k]);
     }
 }
 
 // One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
 // passes (lazy 9-limb form, 36 B); only the first load and the last store use the canonical
-// 32-byte encoding.  LDS: data[9][tile] (limb-major) | tw[9][2^(lp-1)].
+// 32-byte encoding.  LDS: data[9][tile] (limb-major, slots swizzled: swz) | tw[9][2^lp]: the twiddles of stage s,
+// w^(j << (lp - 1 - s)) for j < 2^s, sit at 2^s + j, so that the lanes of a wavefront read neighbouring words at every stage
+// (one table of w^i indexed i = j << (lp - 1 - s) puts the late stages' few distinct twiddles all on one bank).
 //   IN_CANON : `in` holds canonical elements (first pass), else lazy Fr elements (scratch)
 //   FINAL    : last pass: contiguous digit, digit-reversed (natural-order) canonical store
 template <bool FINAL, bool IN_CANON>
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     const uint32_t t = threadIdx.x;
     const uint32_t lp = P.lp, g = P.g, G = 1u << g;
     const uint32_t tile = 1u << (lp + g);
-    const uint32_t ntw = lp ? (1u << (lp - 1)) : 1u;
+    const uint32_t ntw = 1u << lp;
     uint32_t *data = lds;
     uint32_t *tw = lds + NL * tile;
     // blockIdx.y = index of the transform inside a batch of independent, contiguous transforms
@@ -135,7 +151,10 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     const uint32_t *in_c = static_cast<const uint32_t *>(in_v) + boff * 8;
     const Fr *in_l = static_cast<const Fr *>(in_v) + boff;
 
-    for (uint32_t i = t; i < ntw; i += NTT_NT) lds_st(tw, ntw, i, tile_tw[(size_t)i << P.tw_shift]);
+    for (uint32_t i = t + 1; i < ntw; i += NTT_NT) {
+        const uint32_t st = 31u - (uint32_t)__clz((int)i), j = i - (1u << st);
+        lds_st(tw, ntw, i, tile_tw[(size_t)(j << (lp - 1 - st)) << P.tw_shift]);
+    }
 
     const uint32_t tile_id = blockIdx.x;
     uint32_t base_addr = 0, mid = 0, k1_base = 0, mid_in = 0;
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
         for (uint32_t e = t; e < tile; e += NTT_NT) {
             const uint32_t j = e >> g, c = e & (G - 1u);
             const size_t addr = (size_t)base_addr + ((size_t)j << P.sp) + c;
-            lds_st(data, tile, e, IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
+            lds_st(data, tile, swz(e), IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
         }
     } else {
         const uint32_t lmid_tot = (P.nmid > 0 ? P.lmid[0] : 0) + (P.nmid > 1 ? P.lmid[1] : 0);
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
         for (uint32_t e = t; e < tile; e += NTT_NT) {
             const uint32_t c = e >> lp, j = e & ((1u << lp) - 1u);
             const size_t addr = ((size_t)(k1_base + c) << (P.L - P.l1)) + ((size_t)mid_in << lp) + j;
-            lds_st(data, tile, (j << g) | c, IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
+            lds_st(data, tile, swz((j << g) | c), IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
         }
     }
     __syncthreads();
@@ -178,10 +197,10 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     if (!FINAL) {
         Fr *out_l = static_cast<Fr *>(out_v) + boff;
         const uint32_t sh = P.L - lp - P.sp;
-        for (uint32_t e = t; e < tile; e += NTT_NT) {
-            const uint32_t k = e >> g, c = e & (G - 1u);
-            const uint32_t jpos = lp ? (__brev(k) >> (32 - lp)) : 0u;
-            Fr x = lds_ld(data, tile, (jpos << g) | c);
+        for (uint32_t e = t; e < tile; e += NTT_NT) {   // in LDS order: the digit comes out bit-reversed, k = brev(position)
+            const uint32_t jpos = e >> g, c = e & (G - 1u);
+            const uint32_t k = lp ? (__brev(jpos) >> (32 - lp)) : 0u;
+            Fr x = lds_ld(data, tile, swz(e));
             const uint32_t rem = (mid << g) + c;
             const uint32_t ex = (k * rem) << sh;
             // boundaries up to 2^24 entries keep the ready-made twiddle per (k, rem); larger ones build it from the
@@ -201,9 +220,9 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             lmid_tot = P.lmid[0] + P.lmid[1];
         }
         for (uint32_t e = t; e < tile; e += NTT_NT) {
-            const uint32_t k = e >> g, c = e & (G - 1u);
-            const uint32_t jpos = lp ? (__brev(k) >> (32 - lp)) : 0u;
-            Fr x = lds_ld(data, tile, (jpos << g) | c);
+            const uint32_t jpos = e >> g, c = e & (G - 1u);
+            const uint32_t k = lp ? (__brev(jpos) >> (32 - lp)) : 0u;
+            Fr x = lds_ld(data, tile, swz(e));
             if (P.apply_scale) x = fe_mul(x, scale);
             const size_t oidx = (size_t)(k1_base + c) + (((size_t)kmid + ((size_t)k << lmid_tot)) << P.l1);
             st_canon_2r(out_c + oidx * 8, x);
@@ -401,7 +420,7 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
             const void *src = (p == 0) ? static_cast<const void *>(data) : tmp_.p;
             void *dst = final_pass ? static_cast<void *>(data) : tmp_.p;
             const uint32_t tile = 1u << (lp + P.g);
-            const size_t lds = ((size_t)NL * tile + NL * (lp ? (1u << (lp - 1)) : 1u)) * sizeof(uint32_t);
+            const size_t lds = ((size_t)NL * tile + (size_t)NL * (1u << lp)) * sizeof(uint32_t);
             const unsigned blocks = (unsigned)(n >> (lp + P.g));
             if (!final_pass) {
                 const Fr *B = (inverse && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
