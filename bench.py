@@ -49,6 +49,22 @@ def _free_port():
         return so.getsockname()[1]
 
 
+def committed_issue_rate(kernel):
+    """The kernel's vector-ALU issue rate from the committed counter pass (profiles/*_pmc_sq_summary.csv, written by
+    tools/collect_profiles.py: SQ_INSTS_VALU per SIMD cycle, the kernel running alone under rocprofv3 --pmc).  Not measured by this
+    run: quoted next to the live numbers, with its source; None when the file is absent."""
+    import csv, glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq_summary.csv")))
+    if not found:
+        return None
+    for r in csv.DictReader(open(found[-1])):
+        if r["kernel"] == kernel:
+            v = float(r["valu_insts_per_simd_cycle"])
+            return {"source": os.path.relpath(found[-1], ROOT), "insts_per_simd_cycle": v, "peak": 0.25, "frac": v / 0.25,
+                    "note": "a wave64 vector instruction occupies a SIMD for 4 cycles; counters of a separate rocprofv3 --pmc run, not of this one"}
+    return None
+
+
 def launch_command(argv, n_ranks, port):
     """The child command of `bench.py --gpus N`: one rank per GPU under torch.distributed.run, same arguments."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
@@ -521,6 +537,9 @@ def main():
                # independent multiply-adds, as tools/ubench.hip) against the multiply-adds one mixed addition compiles to
                "mad_floor": {"v_mad_u64_u32_lane_ops_per_s": mad_rate, "mads_per_madd": MADS_PER_MADD, "floor_ms": madds * MADS_PER_MADD / mad_rate * 1e3,
                              "frac": (madds * MADS_PER_MADD / mad_rate) / acc_s if acc_s > 0 else 0.0}}
+        pmc = committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >")
+        if pmc:
+            alu["valu_issue_pmc"] = pmc
 
     # ---- secondary: Groth16 prove() wall-clock on a synthetic 2^20-constraint R1CS (BASELINE.json configs[3])
     if args.groth16_log_m and world == 1:
