@@ -193,9 +193,12 @@ def main():
     def run_steps(k, stage_acc=None):
         """k complete steps: every step's pipeline, read-back, host fold and -- for N > 1 -- its exchange and rank-order fold
         finish before this returns.  A lane is refilled as soon as its result has been collected; the exchange of the
-        collected partial is started after that refill and waited for one step later (zkhip.distributed.PartialGather), so
-        neither the collective nor the Python around it sits between a lane finishing and its next submission."""
-        res, pending, exchange, submitted = None, [], None, 0
+        collected partial is started after that refill (zkhip.distributed.PartialGather) and finished when it has landed, at
+        the latest three steps later: the collective's small kernel queues behind MSM grids that keep every CU full, and
+        a host that waits for it (0.5-0.8 ms at a time while the lanes still run in step after a start) is a host that does
+        not refill the lanes."""
+        res, pending, exchanges, submitted = None, [], [], 0
+        lag = 3 if dist_on else 0
 
         def submit():
             nonlocal submitted
@@ -209,24 +212,29 @@ def main():
             return out
 
         def post(out):
-            nonlocal res, exchange
+            nonlocal res
             if not dist_on:
                 res = out
                 return
-            started = sharded_msm_start(_lib.GROUP_G1, out, device=xdev, group=xgroup)
-            if exchange is not None:
-                res = exchange.result()
-            exchange = started
+            exchanges.append(sharded_msm_start(_lib.GROUP_G1, out, device=xdev, group=xgroup))
+            while exchanges and (len(exchanges) > lag or exchanges[0].done()):   # in order: every step's result is folded
+                res = exchanges.pop(0).result()
 
+        trace = [] if os.environ.get("ZK_BENCH_TRACE") else None
+        tr0 = time.perf_counter()
         while submitted < k and len(pending) < depth:
             submit()
         while pending:
             out = collect()
+            if trace is not None:
+                trace.append(round((time.perf_counter() - tr0) * 1e3, 2))
             if submitted < k:
                 submit()
             post(out)
-        if exchange is not None:
-            res = exchange.result()
+        while exchanges:
+            res = exchanges.pop(0).result()
+        if trace is not None:
+            sys.stderr.write("TRACE k=%d end=%.2f collects at %s\n" % (k, (time.perf_counter() - tr0) * 1e3, trace))
         return res
 
     def fence():
@@ -243,8 +251,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     result = run_steps(args.steps, stage)
+    t_steps = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    t_fence = elapsed - t_steps
     if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -265,6 +275,8 @@ def main():
     verified = (got == expect)
 
     extra = {"verified_closed_form": bool(verified), "window_bits": plan.window_bits(n),
+             "timed_region_ms": {"steps": round(t_steps * 1e3, 3), "closing_barrier_and_sync": round(t_fence * 1e3, 3),
+                                 "total_max_over_ranks": round(elapsed * 1e3, 3)},
              "stage_ms": {"prepare": round(float(stage[0]), 4), "sort": round(float(stage[1]), 4), "accumulate": round(float(stage[2]), 4),
                           "reduce": round(float(stage[3]), 4)}}
 

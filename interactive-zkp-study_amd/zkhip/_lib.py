@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libzkhip.so")
+# ZKHIP_LIB: another build of the same library (A/B timing of two builds in one session, tools/ab_ntt.py); default: the in-tree one
+LIB_PATH = os.environ.get("ZKHIP_LIB") or os.path.join(_PKG_DIR, "libzkhip.so")
 
 ZK_OK = 0
 ZK_ERR_INVALID = -1

@@ -24,7 +24,7 @@ def shard_range(n, rank, world_size):
 
 
 _gather_ctx = {}
-_RING = 4   # exchanges that may be in flight per (device, size, world)
+_RING = 6   # exchanges that may be in flight per (device, size, world)
 
 
 class PartialGather:
@@ -38,6 +38,10 @@ class PartialGather:
 
     def __init__(self, slot=None, event=None, value=None):
         self._slot, self._event, self._value = slot, event, value
+
+    def done(self):
+        """True when .result() would not block (the copy-out has landed)."""
+        return self._value is not None or self._event.query()
 
     def result(self):
         """-> uint64[world, L] (rank order)."""
@@ -112,6 +116,9 @@ class ShardedMsmResult:
 
     def __init__(self, group_id, gather):
         self._group_id, self._gather = group_id, gather
+
+    def done(self):
+        return self._gather.done()
 
     def result(self):
         return fold_partials(self._group_id, self._gather.result())
