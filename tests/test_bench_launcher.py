@@ -68,3 +68,27 @@ def test_arithmetic_dot_host_and_device_agree_with_big_integers():
     d = sy.random_scalars_device(50000, "cpu", 5)
     vals = _lib.limbs_to_ints(d.numpy().view(np.uint64))
     assert max(vals) < sy.R_MOD and max(vals).bit_length() >= 252 and len(set(vals)) == len(vals)
+
+
+def test_committed_issue_rate_reads_the_profile_or_returns_none(tmp_path):
+    """roofline.alu.valu_issue_pmc quotes profiles/*_pmc_sq_summary.csv (tools/collect_profiles.py); a kernel that is not in
+    the file, or no file at all, gives None instead of a made-up figure."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    got = mod.committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >")
+    assert got is not None and got["peak"] == 0.25 and 0.0 < got["frac"] <= 1.0 and got["source"].startswith("profiles/")
+    assert abs(got["frac"] - got["insts_per_simd_cycle"] / 0.25) < 1e-12
+    assert mod.committed_issue_rate("no_such_kernel") is None
+    root = mod.ROOT
+    mod.ROOT = str(tmp_path)
+    try:
+        assert mod.committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >") is None
+    finally:
+        mod.ROOT = root
