@@ -109,6 +109,9 @@ def main():
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
     ap.add_argument("--dist-ntt-log-n", type=int, default=24, help="N > 1 only: log2 size of the single NTT spread over all GPUs (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
+    ap.add_argument("--no-rewarm", action="store_true", help="N > 1: no untimed steps between the opening barrier and the start of the clock")
+    ap.add_argument("--stagger-us", type=int, default=0, help="pause between the first submissions of a run of steps, so that the lanes "
+                    "start a third of a step apart instead of together")
     ap.add_argument("--rehearse", action="store_true", help="N > 1 with fewer than N devices: the ranks share the visible devices and talk over gloo "
                     "(checks the N-rank code path; the numbers are not a scaling measurement)")
     ap.add_argument("--dry-launch", action="store_true", help="N > 1: print the child command instead of running it")
@@ -190,15 +193,62 @@ def main():
     depth = plan.max_in_flight() if n <= (1 << 22) else 1   # larger MSMs already run as 2^22-point chunks through all lanes
     xdev, xgroup = (None, host_group) if (dist_on and host_group is not None) else (cdev, None)
 
+    class ExchangeWorker:
+        """The exchange side of the multi-rank step loop, on a thread of its own: it starts the all-gather of every collected
+        partial (zkhip.distributed.sharded_msm_start), finishes the exchanges in order and folds them.  That is ~0.1 ms of
+        Python, RCCL launch and host arithmetic per step; on the submitting thread it sat between a lane finishing and its next
+        submission (0.03-0.1 ms per step when the lanes run in step), here it runs while that thread blocks inside
+        zk_msm_collect (ctypes releases the GIL).  All collectives of the step loop are issued by this one thread, in step
+        order; flush() returns when every exchange handed over has been folded, so nothing is in flight when the caller goes
+        on to a barrier."""
+
+        def __init__(self):
+            import queue
+            import threading
+            self.q, self.idle, self.res, self.err = queue.Queue(), threading.Event(), None, None
+            self.idle.set()
+            threading.Thread(target=self._run, daemon=True).start()
+
+        def _run(self):
+            torch.cuda.set_device(dev_index)      # the current device is per thread
+            inflight = []
+            while True:
+                item = self.q.get()
+                try:
+                    if item is None:               # flush: finish everything, in order
+                        while inflight:
+                            self.res = inflight.pop(0).result()
+                        self.idle.set()
+                        continue
+                    if self.err is None:
+                        inflight.append(sharded_msm_start(_lib.GROUP_G1, item, device=xdev, group=xgroup))
+                        while inflight and (len(inflight) > 3 or inflight[0].done()):
+                            self.res = inflight.pop(0).result()
+                except BaseException as exc:       # noqa: BLE001 -- handed to the submitting thread by flush()
+                    self.err = exc
+                    inflight.clear()
+                    if item is None:
+                        self.idle.set()
+
+        def post(self, partial):
+            self.idle.clear()
+            self.q.put(partial)
+
+        def flush(self):
+            self.q.put(None)
+            self.idle.wait()
+            if self.err is not None:
+                err, self.err = self.err, None
+                raise err
+            return self.res
+
+    worker = ExchangeWorker() if dist_on else None
+
     def run_steps(k, stage_acc=None):
         """k complete steps: every step's pipeline, read-back, host fold and -- for N > 1 -- its exchange and rank-order fold
-        finish before this returns.  A lane is refilled as soon as its result has been collected; the exchange of the
-        collected partial is started after that refill (zkhip.distributed.PartialGather) and finished when it has landed, at
-        the latest three steps later: the collective's small kernel queues behind MSM grids that keep every CU full, and
-        a host that waits for it (0.5-0.8 ms at a time while the lanes still run in step after a start) is a host that does
-        not refill the lanes."""
-        res, pending, exchanges, submitted = None, [], [], 0
-        lag = 3 if dist_on else 0
+        finish before this returns.  A lane is refilled as soon as its result has been collected; for N > 1 the collected
+        partial goes to the exchange thread (ExchangeWorker), which is flushed before this returns."""
+        res, pending, submitted = None, [], 0
 
         def submit():
             nonlocal submitted
@@ -211,28 +261,26 @@ def main():
                 np.add(stage_acc, plan.stage_ms(), out=stage_acc)
             return out
 
-        def post(out):
-            nonlocal res
-            if not dist_on:
-                res = out
-                return
-            exchanges.append(sharded_msm_start(_lib.GROUP_G1, out, device=xdev, group=xgroup))
-            while exchanges and (len(exchanges) > lag or exchanges[0].done()):   # in order: every step's result is folded
-                res = exchanges.pop(0).result()
-
+        while submitted < k and len(pending) < depth:
+            if pending and args.stagger_us:      # see --stagger-us
+                t_go = time.perf_counter() + args.stagger_us * 1e-6
+                while time.perf_counter() < t_go:
+                    pass
+            submit()
         trace = [] if os.environ.get("ZK_BENCH_TRACE") else None
         tr0 = time.perf_counter()
-        while submitted < k and len(pending) < depth:
-            submit()
         while pending:
             out = collect()
             if trace is not None:
                 trace.append(round((time.perf_counter() - tr0) * 1e3, 2))
             if submitted < k:
                 submit()
-            post(out)
-        while exchanges:
-            res = exchanges.pop(0).result()
+            if dist_on:
+                worker.post(out)
+            else:
+                res = out
+        if dist_on:
+            res = worker.flush()
         if trace is not None:
             sys.stderr.write("TRACE k=%d end=%.2f collects at %s\n" % (k, (time.perf_counter() - tr0) * 1e3, trace))
         return res
@@ -249,6 +297,13 @@ def main():
         run_steps(args.warmup)
     stage = np.zeros(4)
     fence()
+    if dist_on and not args.no_rewarm:
+        # The barrier costs the host a millisecond or two, in which the chip idles and clocks down (the first timed steps
+        # then cost 2 ms more on one rank than without the barrier: profiles/r02_experiments.md).  Three more untimed steps
+        # bring the clock back; every rank does the same three steps, so the ranks still start together, and the device is
+        # synchronised once more before the clock starts.
+        run_steps(3)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     result = run_steps(args.steps, stage)
     t_steps = time.perf_counter() - t0
