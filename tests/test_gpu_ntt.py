@@ -1,6 +1,5 @@
 """GPU parity tests (-m gpu): the HIP NTT, through the C ABI, bit-exact against the oracle and the
 golden fixtures; round trips and Horner spot checks at the BASELINE.json size (2^22)."""
-import ctypes
 import json
 import os
 

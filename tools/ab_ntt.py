@@ -3,7 +3,7 @@
     python tools/ab_ntt.py new
     python tools/ab_ntt.py path/to/other/libzkhip.so
 Run both in ONE gpurun call, alternately: box-to-box and clock differences are larger than most kernel changes."""
-import sys, os, time, json
+import sys, os, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/ -> repo root
 sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))

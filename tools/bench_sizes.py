@@ -6,7 +6,7 @@ import argparse, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
-from zkhip.synthetic import random_scalars, limbs_dot_mod_r, R_MOD
+from zkhip.synthetic import random_scalars, limbs_dot_mod_r
 
 
 from zkhip.synthetic import arithmetic_dot, arithmetic_points  # noqa: E402
@@ -23,7 +23,7 @@ def main():
     import torch
     from zkhip import _lib
     from zkhip.device import MsmPlan, NttPlan
-    from zkhip.field import G1, G2, ec_mul, limbs_to_g1, limbs_to_g2, g2_to_limbs
+    from zkhip.field import G1, G2, ec_mul, g2_to_limbs
     lib = _lib.load()
     _lib.check(lib.zk_test_set_msm_chunk_log(args.chunk_log))
     st = torch.cuda.current_stream().cuda_stream

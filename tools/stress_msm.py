@@ -2,7 +2,7 @@
 """Randomised stress of the MSM pipeline on one GPU: random sizes (including chunked ones through the test knob),
 scalar patterns, in-flight depths and the bound-bases mode, every result checked against the closed form (sum s_i k_i) * G.
     python tools/stress_msm.py --iters 60 [--seed 1]"""
-import argparse, os, sys, time
+import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
 import numpy as np
@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--max-log", type=int, default=19)
     a = ap.parse_args()
     import torch
-    from zkhip.synthetic import random_scalars, limbs_dot_mod_r, R_MOD
+    from zkhip.synthetic import random_scalars, limbs_dot_mod_r
     from zkhip import _lib
     from zkhip.device import MsmPlan
     from zkhip.field import G1, G2, ec_mul, g2_to_limbs, limbs_to_g1, limbs_to_g2
