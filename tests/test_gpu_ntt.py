@@ -110,11 +110,13 @@ def test_ntt_2pow22_round_trip_and_horner():
     assert np.array_equal(d.cpu().numpy().view(np.uint64), X)
 
 
-def test_ntt_2pow22_bit_exact_vs_oracle():
-    """BASELINE.json configs[2] in full: every one of the 2^22 outputs against the oracle's recursive radix-2 NTT."""
+@pytest.mark.parametrize("L", [22, 21, 23])
+def test_ntt_2pow22_bit_exact_vs_oracle(L):
+    """BASELINE.json configs[2] in full: every one of the 2^22 outputs against the oracle's recursive radix-2 NTT -- and the
+    two neighbouring sizes, whose digit splits (8 + 7 + 6 and 8 + 8 + 7: one odd digit, i.e. a single-stage last round in one
+    pass) the sizes up to 2^20 and 2^22 = 8 + 8 + 6 do not reach."""
     import torch
-    rng = np.random.default_rng(2222)
-    L = 22
+    rng = np.random.default_rng(2200 + L)
     n = 1 << L
     X = _fast_rand(rng, n)
     d = torch.from_numpy(X.view(np.int64).copy()).cuda()
