@@ -237,6 +237,48 @@ template <int K, class Tag> ZK_HD Fe<Tag> fe_neg_k(const Fe<Tag> &a) {
     ZK_DBG(r.vb = K;)
     return r;
 }
+// a + b brought below 2m, for normalised a, b < 2m: the same representative as fe_add followed by fe_wreduce<4>, with ONE carry
+// chain instead of two.  Whether 2m has to come off is read from the top limbs before any carry is propagated: with
+// t = a_8 + b_8 - (2m)_8, the lower limbs of the sum add less than 2 * 2^232 and those of 2m less than 2^232, so
+//   t >= 1  =>  a + b - 2m > 0  (subtract),     t <= -2  =>  a + b - 2m < 0  (leave),
+// and only t in {-1, 0} (probability 2^-22 for a uniform top limb) needs the full comparison: that case takes the two-chain path.
+template <class Tag> ZK_HD Fe<Tag> fe_add_r2(const Fe<Tag> &a, const Fe<Tag> &b) {
+    typedef FieldConst<Tag> C;
+    ZK_DBG_ASSERT(a.vb <= 2 && b.vb <= 2 && a.lmax <= 1 && b.lmax <= 1, "fe_add_r2: operands must be normalised and < 2m");
+    const int32_t t = (int32_t)(a.l[NL - 1] + b.l[NL - 1]) - (int32_t)C::kp(2, NL - 1);
+    Fe<Tag> r;
+    if ((uint32_t)(t + 1) <= 1u) {
+        r = fe_add(a, b);
+        fe_cond_sub<2>(r);
+    } else {
+        const uint32_t take = t > 0 ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i] - (C::kp(2, i) & take);
+        fe_normalize(r);
+        ZK_DBG(r.vb = 2;)
+    }
+    return r;
+}
+// a - b brought into [0, 2m), for normalised a, b < 2m: the same representative as fe_sub_k<2> followed by fe_wreduce<4>.  With
+// t = a_8 - b_8 the lower limbs differ by less than 2^232 either way:  t >= 1 => a - b > 0,  t <= -1 => a - b < 0 (add 2m);
+// t == 0 takes the two-chain path.
+template <class Tag> ZK_HD Fe<Tag> fe_sub_r2(const Fe<Tag> &a, const Fe<Tag> &b) {
+    typedef FieldConst<Tag> C;
+    ZK_DBG_ASSERT(a.vb <= 2 && b.vb <= 2 && a.lmax <= 1 && b.lmax <= 1, "fe_sub_r2: operands must be normalised and < 2m");
+    const int32_t t = (int32_t)a.l[NL - 1] - (int32_t)b.l[NL - 1];
+    Fe<Tag> r;
+    if (t == 0) {
+        r = fe_sub_k<2>(a, b);
+        fe_cond_sub<2>(r);
+    } else {
+        const uint32_t give = t < 0 ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = a.l[i] - b.l[i] + (C::kp(2, i) & give);
+        fe_normalize(r);
+        ZK_DBG(r.vb = 2;)
+    }
+    return r;
+}
 // Unnormalised forms for values that go straight into ONE multiplication (fe_mul / fe_dot / fe_mulsub take limbs
 // up to a few 2^29: 9 * la * lb + 10 < 64 per product column): no carry propagation at all.
 //   fe_sub_lazy<K>: a - b + (K+1)*m, needs b normalised and <= K*m; limbs < (la + 2) * 2^29.

@@ -109,12 +109,10 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
 #pragma unroll
                 for (int hi = 0; hi < (1 << (R - 1 - b)); hi++) {
                     const int k0 = (hi << (b + 1)) | q, k1 = k0 | (1 << b);
-                    Fr sum = fe_add(x[k0], x[k1]);  // < 4r
-                    fe_wreduce<4>(sum);             // < 2r
+                    const Fr sum = fe_add_r2(x[k0], x[k1]);   // < 2r, one carry chain (field.h)
                     Fr dif;
                     if (unit) {
-                        dif = fe_sub_k<2>(x[k0], x[k1]);  // (a - b + 2r) < 4r
-                        fe_wreduce<4>(dif);               // < 2r
+                        dif = fe_sub_r2(x[k0], x[k1]);          // < 2r
                     } else {
                         dif = fe_mul(fe_sub_lazy<2>(x[k0], x[k1]), w);  // (a - b + 3r) < 5r, w < r  ->  < 2r
                     }

@@ -59,7 +59,29 @@ static void g2_store(uint64_t *o, const G2Xyzz &p) {
 }
 static void k32(const uint64_t *k, uint32_t out[8]) { words_of(k, out); }
 
+// fe_add_r2 / fe_sub_r2 against the two-chain forms they replace, on RAW normalised 9-limb operands (values < 2m): both results
+// as raw limbs, so the test can demand the very same representative.  which: 0 = F_p, 1 = F_r; op: 0 = add, 1 = sub.
+template <class T> static void r2_pair(int op, const uint32_t *a9, const uint32_t *b9, uint32_t *fast9, uint32_t *ref9) {
+    Fe<T> a, b;
+    for (int i = 0; i < NL; i++) { a.l[i] = a9[i]; b.l[i] = b9[i]; }
+    ZK_DBG(a.vb = 2; b.vb = 2; a.lmax = 1; b.lmax = 1;)
+    Fe<T> f, r;
+    if (op == 0) {
+        f = fe_add_r2(a, b);
+        r = fe_add(a, b);
+        fe_wreduce<4>(r);
+    } else {
+        f = fe_sub_r2(a, b);
+        r = fe_sub_k<2>(a, b);
+        fe_wreduce<4>(r);
+    }
+    for (int i = 0; i < NL; i++) { fast9[i] = f.l[i]; ref9[i] = r.l[i]; }
+}
+
 extern "C" {
+void hm_r2_pair(int which, int op, const uint32_t *a9, const uint32_t *b9, uint32_t *fast9, uint32_t *ref9) {
+    if (which) r2_pair<FrTag>(op, a9, b9, fast9, ref9); else r2_pair<FpTag>(op, a9, b9, fast9, ref9);
+}
 void hm_field_op(int which, int op, const uint64_t *a, const uint64_t *b, uint64_t *o) {
     if (which) field_op<FrTag>(op, a, b, o); else field_op<FpTag>(op, a, b, o);
 }

@@ -162,3 +162,65 @@ def test_sanitizer_build_is_clean():
     r = subprocess.run([os.path.join(d, "sanitize_check")], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().endswith("sanitize ok")
+
+
+def test_single_chain_reduced_add_and_sub(hm):
+    """fe_add_r2 / fe_sub_r2 (field.h; the NTT butterflies) decide their conditional +-2m from the top limbs and take a slow
+    path when those cannot tell (probability 2^-22 per operation: random transforms never get there).  Against the two-chain
+    forms they replace, same representative limb for limb: uniform operands, sums and differences within a few units and
+    within a few 2^232 of the 2m boundary, and every top-limb constellation around the ambiguous ones with all-zero,
+    all-one and random lower limbs."""
+    rng = np.random.default_rng(2929)
+    mask = (1 << 29) - 1
+
+    def limbs(v):
+        return np.array([(v >> (29 * i)) & mask for i in range(8)] + [v >> 232], dtype=np.uint32)
+
+    def value(l):
+        return sum(int(x) << (29 * i) for i, x in enumerate(l))
+
+    for which, m in ((0, o.P), (1, o.R)):
+        two_m = 2 * m
+        k8 = two_m >> 232
+        rand = lambda: int.from_bytes(rng.bytes(40), "little") % two_m
+        cases = {0: [], 1: []}
+        for _ in range(3000):
+            cases[0].append((rand(), rand()))
+            cases[1].append((rand(), rand()))
+        deltas = [d for e in (0, 1, 2, 3, 1 << 29, 1 << 231, 1 << 232, (1 << 232) + 1, (1 << 232) - 1, 1 << 233) for d in (e, -e)]
+        for _ in range(300):
+            a = rand()
+            for d in deltas:
+                b = two_m - a + d
+                if 0 <= b < two_m:
+                    cases[0].append((a, b))
+                b = a + d
+                if 0 <= b < two_m:
+                    cases[1].append((a, b))
+        lows = [0, (1 << 232) - 1, 1, (1 << 232) - 2]
+        for _ in range(200):
+            a8 = int(rng.integers(0, k8 + 1))
+            for e in (-3, -2, -1, 0, 1, 2, 3):
+                for la in lows + [int.from_bytes(rng.bytes(29), "little")]:
+                    for lb in lows + [int.from_bytes(rng.bytes(29), "little")]:
+                        b8 = k8 - a8 + e                                   # add: a_8 + b_8 - (2m)_8 = e
+                        a, b = (a8 << 232) | la, (b8 << 232) | lb
+                        if b8 >= 0 and a < two_m and b < two_m:
+                            cases[0].append((a, b))
+                        b8 = a8 + e                                        # sub: a_8 - b_8 = -e
+                        b = (b8 << 232) | lb
+                        if b8 >= 0 and a < two_m and b < two_m:
+                            cases[1].append((a, b))
+        fast, ref = np.zeros(9, dtype=np.uint32), np.zeros(9, dtype=np.uint32)
+        for op in (0, 1):
+            amb = 0
+            for a, b in cases[op]:
+                la, lb = limbs(a), limbs(b)
+                hm.hm_r2_pair(which, op, P(la), P(lb), P(fast), P(ref))    # (the debug build also checks every bound contract)
+                assert np.array_equal(fast, ref), (which, op, hex(a), hex(b))
+                want = (a + b) if op == 0 else (a - b)
+                want = want - two_m if want >= two_m else (want + two_m if want < 0 else want)
+                assert value(fast) == want and all(int(x) <= mask for x in fast[:8])
+                t = (int(la[8]) + int(lb[8]) - k8) if op == 0 else (int(la[8]) - int(lb[8]))
+                amb += (t in (-1, 0)) if op == 0 else (t == 0)
+            assert amb > 1000                                              # the slow path was exercised, not just present
