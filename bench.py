@@ -267,7 +267,7 @@ def main():
                 while time.perf_counter() < t_go:
                     pass
             submit()
-        trace = [] if os.environ.get("ZK_BENCH_TRACE") else None
+        trace = [] if os.environ.get("ZK_BENCH_TRACE") else None   # diagnostics: host time of every collect, to stderr
         tr0 = time.perf_counter()
         while pending:
             out = collect()
