@@ -135,7 +135,7 @@ def main():
     import torch.distributed as dist
     from zkhip import _lib
     from zkhip.device import MsmPlan, NttPlan
-    from zkhip.distributed import sharded_msm, sharded_msm_start
+    from zkhip.distributed import ExchangeWorker, sharded_msm
     from zkhip.field import G1, ec_mul, limbs_to_g1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,56 +193,8 @@ def main():
     depth = plan.max_in_flight() if n <= (1 << 22) else 1   # larger MSMs already run as 2^22-point chunks through all lanes
     xdev, xgroup = (None, host_group) if (dist_on and host_group is not None) else (cdev, None)
 
-    class ExchangeWorker:
-        """The exchange side of the multi-rank step loop, on a thread of its own: it starts the all-gather of every collected
-        partial (zkhip.distributed.sharded_msm_start), finishes the exchanges in order and folds them.  That is ~0.1 ms of
-        Python, RCCL launch and host arithmetic per step; on the submitting thread it sat between a lane finishing and its next
-        submission (0.03-0.1 ms per step when the lanes run in step), here it runs while that thread blocks inside
-        zk_msm_collect (ctypes releases the GIL).  All collectives of the step loop are issued by this one thread, in step
-        order; flush() returns when every exchange handed over has been folded, so nothing is in flight when the caller goes
-        on to a barrier."""
-
-        def __init__(self):
-            import queue
-            import threading
-            self.q, self.idle, self.res, self.err = queue.Queue(), threading.Event(), None, None
-            self.idle.set()
-            threading.Thread(target=self._run, daemon=True).start()
-
-        def _run(self):
-            torch.cuda.set_device(dev_index)      # the current device is per thread
-            inflight = []
-            while True:
-                item = self.q.get()
-                try:
-                    if item is None:               # flush: finish everything, in order
-                        while inflight:
-                            self.res = inflight.pop(0).result()
-                        self.idle.set()
-                        continue
-                    if self.err is None:
-                        inflight.append(sharded_msm_start(_lib.GROUP_G1, item, device=xdev, group=xgroup))
-                        while inflight and (len(inflight) > 3 or inflight[0].done()):
-                            self.res = inflight.pop(0).result()
-                except BaseException as exc:       # noqa: BLE001 -- handed to the submitting thread by flush()
-                    self.err = exc
-                    inflight.clear()
-                    if item is None:
-                        self.idle.set()
-
-        def post(self, partial):
-            self.idle.clear()
-            self.q.put(partial)
-
-        def flush(self):
-            self.q.put(None)
-            self.idle.wait()
-            if self.err is not None:
-                err, self.err = self.err, None
-                raise err
-            return self.res
-
-    worker = ExchangeWorker() if dist_on else None
+    # the exchange side of the multi-rank step loop runs on a thread of its own (zkhip.distributed.ExchangeWorker)
+    worker = ExchangeWorker(_lib.GROUP_G1, device=xdev, group=xgroup, cuda_device=dev_index) if dist_on else None
 
     def run_steps(k, stage_acc=None):
         """k complete steps: every step's pipeline, read-back, host fold and -- for N > 1 -- its exchange and rank-order fold

@@ -129,6 +129,60 @@ def sharded_msm_start(group_id, local_partial, device=None, group=None):
     return ShardedMsmResult(group_id, all_gather_partials_start(local_partial, device=device, group=group))
 
 
+class ExchangeWorker:
+    """The exchange side of a pipelined multi-rank MSM loop, on a thread of its own: post() hands over a collected partial; the
+    thread starts its all-gather (sharded_msm_start), finishes the exchanges in order -- as soon as one has landed, at the latest
+    three posts later -- and folds them.  That is ~0.1 ms of Python, collective launch and host arithmetic per step, which
+    otherwise sits between a lane finishing and its next submission; here it runs while the submitting thread blocks inside
+    zk_msm_collect (ctypes releases the GIL).  All collectives of the loop are issued by this one thread, in post order (the same
+    on every rank); flush() returns the last folded result once every exchange handed over has been folded, so nothing is in
+    flight when the caller goes on to a barrier.  An exception in the thread is re-raised by flush()."""
+
+    def __init__(self, group_id, device=None, group=None, cuda_device=None, lag=3):
+        import queue
+        import threading
+        self._args = (group_id, device, group, cuda_device, lag)
+        self.q, self.idle, self.res, self.err = queue.Queue(), threading.Event(), None, None
+        self.idle.set()
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def _run(self):
+        group_id, device, group, cuda_device, lag = self._args
+        if cuda_device is not None:
+            import torch
+            torch.cuda.set_device(cuda_device)      # the current device is per thread
+        inflight = []
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:                     # flush: finish everything, in order
+                    while inflight:
+                        self.res = inflight.pop(0).result()
+                    self.idle.set()
+                    continue
+                if self.err is None:
+                    inflight.append(sharded_msm_start(group_id, item, device=device, group=group))
+                    while inflight and (len(inflight) > lag or inflight[0].done()):
+                        self.res = inflight.pop(0).result()
+            except BaseException as exc:             # noqa: BLE001 -- handed to the submitting thread by flush()
+                self.err = exc
+                inflight.clear()
+                if item is None:
+                    self.idle.set()
+
+    def post(self, partial):
+        self.idle.clear()
+        self.q.put(partial)
+
+    def flush(self):
+        self.q.put(None)
+        self.idle.wait()
+        if self.err is not None:
+            err, self.err = self.err, None
+            raise err
+        return self.res
+
+
 # ------------------------------------------------------------------------------------------------
 # Single large NTT across GPUs (SURVEY.md section 8 row E2, mode 2): four-step with ONE all-to-all.
 #

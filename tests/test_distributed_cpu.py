@@ -22,7 +22,7 @@ def _worker(rank, world, port, n, ret):
     import py_ref as o
     from test_abi import xyzz_partial_g1
     from zkhip import _lib
-    from zkhip.distributed import shard_range, sharded_msm, sharded_msm_start
+    from zkhip.distributed import ExchangeWorker, shard_range, sharded_msm, sharded_msm_start
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,6 +41,22 @@ def _worker(rank, world, port, n, ret):
         handles = [sharded_msm_start(_lib.GROUP_G1, xyzz_partial_g1(local)) for _ in range(3)]
         ok = ok and all(h.done() for h in handles)            # the host path finishes inside the start call
         ok = ok and all(h.result() == got for h in handles)
+        # and the thread that runs the exchange side of bench.py's multi-rank loop: posts in step order, flush folds the last one
+        worker = ExchangeWorker(_lib.GROUP_G1)
+        for step in range(7):
+            worker.post(xyzz_partial_g1(local if step != 3 else None))   # step 3: this rank contributes infinity
+        ok = ok and worker.flush() == got
+        worker.post(xyzz_partial_g1(None))
+        only_others = worker.flush()                                     # every rank posts infinity: the sum is infinity
+        ok = ok and only_others is None
+        try:
+            worker.post("not a partial")                                 # fails before any collective, on every rank: surfaces at flush()
+            worker.flush()
+            ok = False
+        except Exception:                                                # noqa: BLE001
+            pass
+        worker.post(xyzz_partial_g1(local))                              # and the worker is usable afterwards
+        ok = ok and worker.flush() == got
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
