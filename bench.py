@@ -638,6 +638,7 @@ def main():
                                              "RCCL (nccl backend)" + ("; MSM partials over a host-side gloo group (--exchange host)" if host_group is not None else ""))
         print(json.dumps(line), flush=True)
     if dist_on:
+        worker.close()
         dist.barrier()
         dist.destroy_process_group()
     if not verified:

@@ -72,6 +72,9 @@ int zk_msm_g2(const uint64_t *scalars /* n*4 */, const uint64_t *points /* n*16 
 /* Device-resident MSM.  A plan owns the workspace for MSMs of up to max_n points. */
 typedef struct zk_msm_plan zk_msm_plan;
 int zk_msm_plan_create(int group /* ZK_GROUP_G1|G2 */, size_t max_n, zk_msm_plan **plan);
+/* The same with the chunk size for MSMs of more than 2^chunk_log2 points chosen per plan (12..24; 0 = the default 22 that
+ * zk_msm_plan_create uses).  No reference counterpart: smaller chunks exercise the chunked path at sizes an oracle can check. */
+int zk_msm_plan_create_ex(int group, size_t max_n, int chunk_log2, zk_msm_plan **plan);
 int zk_msm_plan_destroy(zk_msm_plan *plan);
 /* Window width the plan will use for n points (Pippenger c); informational. */
 int zk_msm_plan_window_bits(const zk_msm_plan *plan, size_t n);
@@ -99,8 +102,9 @@ int zk_msm_dev_partial(zk_msm_plan *plan, const void *d_scalars, const void *d_p
  * outstanding; each runs in its own workspace and stream, so consecutive MSMs overlap on the GPU and
  * the host fold of MSM k hides behind MSM k+1 (a prover issues 5-17 MSMs back to back).  Tickets are
  * collected in any order.  An MSM of more than 2^22 points runs as consecutive 2^22-point chunks in
- * those same lanes (partial sums added on the host): it needs all lanes free, zk_msm_submit may block
- * for its early chunks, and it is the only submission outstanding until collected. */
+ * the lanes that are free at that moment (partial sums added on the host; at least one lane must be free): zk_msm_submit
+ * may block for its early chunks, submissions made before it stay collectable by their tickets, and no further
+ * submission is accepted until it has been collected. */
 /* Bound-bases mode.  The bases of a prover's queries never change (CRS / SRS): zk_msm_plan_bind_points expands n device
  * points once into the plan's table T[w][i] = 2^(20 w) * P_i (13 * n packed points: 832 B per G1 point, 1664 B per G2
  * point; the plan must have been created for more than 2^17 points, and 13 n < 2^31).  Afterwards every MSM call of the plan
@@ -239,13 +243,6 @@ int zk_pairing_check(const uint64_t *g1_points /* n*8 */, const uint64_t *g2_poi
  *             hardware multiply-add issue rate, a ceiling that does not depend on this library's field arithmetic.
  */
 int zk_measure_rate(int what, double *out_per_sec);
-
-/* ------------------------------------------------------------------------------------------
- * Test hook (no reference counterpart; not for production use): MSM plans created after this call split
- * inputs into chunks of 2^log2_points points (12..24) instead of 2^22, so that the chunked path can be
- * exercised at sizes an oracle can check.  0 restores the default.  Process-wide.
- */
-int zk_test_set_msm_chunk_log(int log2_points);
 
 #ifdef __cplusplus
 }

@@ -25,11 +25,6 @@ int require_device() {
     return ZK_OK;
 }
 
-int &msm_chunk_log_override() {
-    static int v = 0;
-    return v;
-}
-
 // Plans own device memory, streams and (NTT) a per-device kernel attribute: they work on the device they were created on only.
 static int check_plan_device(int plan_device, const char *who) {
     int cur = -1;
@@ -394,10 +389,18 @@ int zk_msm_plan_create(int group, size_t max_n, zk_msm_plan **plan) {
         return ZK_OK;
     });
 }
-int zk_test_set_msm_chunk_log(int log2_points) {
-    if (log2_points != 0 && (log2_points < 12 || log2_points > 24)) return invalid("zk_test_set_msm_chunk_log: 0 (default) or 12..24");
-    msm_chunk_log_override() = log2_points;
-    return ZK_OK;
+int zk_msm_plan_create_ex(int group, size_t max_n, int chunk_log2, zk_msm_plan **plan) {
+    return guarded([&] {
+        if (!plan || (group != ZK_GROUP_G1 && group != ZK_GROUP_G2) || max_n == 0 || max_n > ((size_t)1 << 30))
+            return invalid("zk_msm_plan_create_ex: bad argument");
+        if (chunk_log2 != 0 && (chunk_log2 < 12 || chunk_log2 > 24)) return invalid("zk_msm_plan_create_ex: chunk_log2 must be 0 (default) or 12..24");
+        int rc = require_device();
+        if (rc) return rc;
+        zk_msm_plan *p = new zk_msm_plan;
+        p->impl.reset(msm_plan_new(group, max_n, true, chunk_log2));
+        *plan = p;
+        return ZK_OK;
+    });
 }
 int zk_msm_plan_destroy(zk_msm_plan *plan) {
     delete plan;

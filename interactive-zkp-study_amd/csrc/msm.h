@@ -25,14 +25,12 @@ struct MsmPlanBase {
     virtual int bind_points(const void *d_points, size_t n, hipStream_t st) = 0;
     virtual int submit_bound(const void *d_scalars, size_t first, size_t n, hipStream_t st) = 0;
 };
-// Test hook (zk_test_set_msm_chunk_log): log2 of the chunk size MSM plans created from now on use; 0 = the default 2^22.
-int &msm_chunk_log_override();
-
-// all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use
-MsmPlanBase *msm_plan_new_g1(size_t max_n, bool all_lanes);
-MsmPlanBase *msm_plan_new_g2(size_t max_n, bool all_lanes);
-inline MsmPlanBase *msm_plan_new(int group, size_t max_n, bool all_lanes = false) {
-    return group == ZK_GROUP_G1 ? msm_plan_new_g1(max_n, all_lanes) : group == ZK_GROUP_G2 ? msm_plan_new_g2(max_n, all_lanes) : nullptr;
+// all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use;
+// chunk_log: log2 of the chunk size for MSMs beyond it (0 = the default 2^22; zk_msm_plan_create_ex)
+MsmPlanBase *msm_plan_new_g1(size_t max_n, bool all_lanes, int chunk_log);
+MsmPlanBase *msm_plan_new_g2(size_t max_n, bool all_lanes, int chunk_log);
+inline MsmPlanBase *msm_plan_new(int group, size_t max_n, bool all_lanes = false, int chunk_log = 0) {
+    return group == ZK_GROUP_G1 ? msm_plan_new_g1(max_n, all_lanes, chunk_log) : group == ZK_GROUP_G2 ? msm_plan_new_g2(max_n, all_lanes, chunk_log) : nullptr;
 }
 
 // Host XYZZ (Montgomery) -> canonical affine limbs; infinity -> zeros + flag.

@@ -774,10 +774,18 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     static uint32_t *err_dev(Lane &L) { return L.out.template as<uint32_t>(); }
     static Xyzz<F> *out_dev(Lane &L) { return reinterpret_cast<Xyzz<F> *>(static_cast<char *>(L.out.p) + OUT_HDR); }
     static const Xyzz<F> *out_host(const Lane &L) { return reinterpret_cast<const Xyzz<F> *>(static_cast<const char *>(L.h_out.p) + OUT_HDR); }
+    // A launch that throws half-way through a submission must not leave the lane marked busy, and whatever the kernels that did
+    // start added to the lane's device error counter must not be charged to the next (valid) submission: wait for the lane and
+    // re-read the counter.
     struct LaneGuard {
         Lane *lane;
         ~LaneGuard() {
-            if (lane) lane->busy = false;
+            if (!lane) return;
+            lane->busy = false;
+            uint32_t now = 0;
+            if (lane->stream && hipStreamSynchronize(lane->stream) == hipSuccess &&
+                hipMemcpy(&now, lane->out.p, sizeof(now), hipMemcpyDeviceToHost) == hipSuccess)
+                lane->err_seen = now;
         }
     };
     static constexpr int MAX_LANES = 3;
@@ -791,8 +799,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // host): the packed bases of a chunk (256 MB) stay within reach of the Infinity Cache and the TLB -- at 2^26 in one
     // piece the gathers of the accumulate kernel run 40 % slower -- and the chunks overlap like any other submissions
     // (2^24: 26.3 -> 24.0 ms, 2^26: 138 -> 93 ms).  The workspace never exceeds that of a 2^22-point MSM.
-    static size_t chunk_points() {  // 2^22 unless a test moved it (zk_test_set_msm_chunk_log: chunking at sizes the oracle can check)
-        const int l = msm_chunk_log_override() ? msm_chunk_log_override() : 22;
+    // 2^22 unless the plan was created with another chunk size (zk_msm_plan_create_ex: chunking at sizes the oracle can check)
+    static size_t chunk_points(int chunk_log) {
+        const int l = chunk_log ? chunk_log : 22;
         return (size_t)1 << (l < 12 ? 12 : l > 24 ? 24 : l);
     }
     static constexpr int BIG_TICKET = 64;
@@ -804,10 +813,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         int npend = 0;
     } big;
 
-    explicit MsmPlanImpl(size_t max_n_, bool all_lanes = false) : max_n(max_n_) {
+    explicit MsmPlanImpl(size_t max_n_, bool all_lanes = false, int chunk_log = 0) : max_n(max_n_) {
         group = sizeof(F) == sizeof(Fp) ? ZK_GROUP_G1 : ZK_GROUP_G2;
         ZK_HIP(hipGetDevice(&device));
-        cap_n = std::min(max_n, chunk_points());
+        cap_n = std::min(max_n, chunk_points(chunk_log));
         const size_t n_pad = pad_n(cap_n);
         // worst case over the window choices available to n <= max_n
         const int cs[3] = {8, 15, 16};
@@ -827,6 +836,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             // Prime every lane with a one-point MSM: the first launches on a new stream pay for the hardware queue and the
             // code objects (milliseconds), which would otherwise land on the caller's first three submissions.
             ZK_HIP(hipMemset(lanes[0].arena.p, 0, 128));
+            ZK_HIP(hipStreamSynchronize(0));  // null-stream memset vs the lanes' non-blocking streams
             const bool prof = profile;
             profile = true;  // creates the profiling events as well
             for (int i = 0; i < nlanes; i++) (void)collect_lane(submit_lane(lanes[0].arena.p, lanes[0].arena.p, 1, nullptr));
@@ -857,6 +867,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.out.alloc(out_bytes_max + OUT_HDR);
         ZK_HIP(hipMemset(L.out.p, 0, OUT_HDR));
         L.h_out.alloc(out_bytes_max + OUT_HDR);
+        // the memsets above were issued on the null stream, which the lane's non-blocking stream does not wait for: make sure they
+        // have landed before the lane's first kernel can run (it bumps the error counter in the header zeroed here)
+        ZK_HIP(hipStreamSynchronize(0));
         ZK_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         L.ready = true;
@@ -1046,8 +1059,11 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // n > CHUNK: every chunk is an ordinary submission; when the lanes run out the oldest chunk is collected (this call
     // then blocks for it).  The ticket stands for the whole MSM; no other submission may be outstanding meanwhile.
     int submit_chunked(const void *d_scalars, const void *d_points, size_t first, size_t n, hipStream_t st) {
-        for (int i = 0; i < nlanes; i++)
-            if (lanes[i].busy) throw std::runtime_error("zk_msm: an MSM of more than 2^22 points needs all lanes free; collect first");
+        // The chunks rotate through the lanes that are free now: submissions made earlier (a prover's other queries) stay in
+        // flight in theirs and are collected by their own tickets, in any order.  With every lane taken there is nowhere to run.
+        int nfree = 0;
+        for (int i = 0; i < nlanes; i++) nfree += lanes[i].busy ? 0 : 1;
+        if (!nfree) throw std::runtime_error("zk_msm: an MSM of more than 2^22 points needs a free lane; collect an outstanding submission first");
         big.active = true;
         big.acc = Xyzz<HF>::inf();
         big.npend = 0;
@@ -1055,12 +1071,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         try {
             for (size_t off = 0; off < n; off += cap_n) {
                 const size_t m = std::min(cap_n, n - off);
-                if (big.npend == nlanes) {
-                    const int oldest = big.pend[0];
+                int lane = -1;
+                for (int k = 0; k < nlanes && lane < 0; k++)
+                    if (!lanes[(next_lane + k) % nlanes].busy) lane = (next_lane + k) % nlanes;
+                if (lane < 0) {  // all free lanes hold chunks of this MSM: collect the oldest, its lane is free again
+                    lane = big.pend[0];
                     for (int i = 1; i < big.npend; i++) big.pend[i - 1] = big.pend[i];
                     big.npend--;
-                    xyzz_add(big.acc, collect_lane(oldest));
+                    xyzz_add(big.acc, collect_lane(lane));
                 }
+                next_lane = lane;
                 big.pend[big.npend++] = d_points ? submit_lane(sc + off * 8, pt + off * 2 * F::CANON_WORDS, m, st) : submit_lane_fixed(sc + off * 8, first + off, m, st);
             }
         } catch (...) {

@@ -10,8 +10,9 @@ import os
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# ZKHIP_LIB: another build of the same library (A/B timing of two builds in one session, tools/ab_ntt.py); default: the in-tree one
-LIB_PATH = os.environ.get("ZKHIP_LIB") or os.path.join(_PKG_DIR, "libzkhip.so")
+# The in-tree build.  The A/B tools (tools/ab_ntt.py, tools/ab_msm.py) point LIB_PATH at another build of the same ABI before the
+# first load(); no environment variable redirects the product path.
+LIB_PATH = os.path.join(_PKG_DIR, "libzkhip.so")
 
 ZK_OK = 0
 ZK_ERR_INVALID = -1
@@ -40,6 +41,7 @@ _PROTOS = {
     "zk_msm_g1": (ctypes.c_int, [_VP, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
     "zk_msm_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
     "zk_msm_plan_create": (ctypes.c_int, [ctypes.c_int, _SZ, ctypes.POINTER(_VP)]),
+    "zk_msm_plan_create_ex": (ctypes.c_int, [ctypes.c_int, _SZ, ctypes.c_int, ctypes.POINTER(_VP)]),
     "zk_msm_plan_destroy": (ctypes.c_int, [_VP]),
     "zk_msm_plan_window_bits": (ctypes.c_int, [_VP, _SZ]),
     "zk_msm_plan_max_in_flight": (ctypes.c_int, [_VP]),
@@ -73,7 +75,6 @@ _PROTOS = {
     "zk_fixed_base_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_group_op": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, _VP, _SZ, _VP]),
     "zk_measure_rate": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
-    "zk_test_set_msm_chunk_log": (ctypes.c_int, [ctypes.c_int]),
     "zk_pairing": (ctypes.c_int, [_VP, _VP, _VP]),
     "zk_pairing_check": (ctypes.c_int, [_VP, _VP, _SZ, ctypes.POINTER(ctypes.c_int)]),
 }

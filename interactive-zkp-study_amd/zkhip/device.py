@@ -15,11 +15,16 @@ from .field import limbs_to_g1, limbs_to_g2
 class MsmPlan:
     """Workspace + pipeline for G1/G2 MSMs of up to max_n points (zk_msm_plan_*)."""
 
-    def __init__(self, group, max_n):
+    def __init__(self, group, max_n, chunk_log=0):
+        """chunk_log: MSMs of more than 2^chunk_log points run as chunks of that size (0 = the library's 2^22;
+        zk_msm_plan_create_ex)."""
         self.group = group
         self.max_n = int(max_n)
         self._h = ctypes.c_void_p()
-        _lib.check(_lib.load().zk_msm_plan_create(group, self.max_n, ctypes.byref(self._h)))
+        if chunk_log:
+            _lib.check(_lib.load().zk_msm_plan_create_ex(group, self.max_n, int(chunk_log), ctypes.byref(self._h)))
+        else:
+            _lib.check(_lib.load().zk_msm_plan_create(group, self.max_n, ctypes.byref(self._h)))
         self._limbs = 8 if group == _lib.GROUP_G1 else 16
 
     def close(self):

@@ -51,6 +51,14 @@ class PartialGather:
             self._slot["busy"] = False
         return self._value
 
+    def abandon(self):
+        """Gives the ring slot back without reading the result (error paths): waits for whatever was enqueued on it."""
+        if self._value is None and self._slot is not None:
+            try:
+                self._event.synchronize()
+            finally:
+                self._slot["busy"] = False
+
 
 def all_gather_partials_start(partial, device=None, group=None):
     """partial: uint64[L] on the host -> PartialGather.  Buffers are allocated once per (device, size, world), as a ring."""
@@ -75,9 +83,9 @@ def all_gather_partials_start(partial, device=None, group=None):
                                  "event": torch.cuda.Event(), "busy": False, "world": world})
         _gather_ctx[key] = ctx
     slot = ctx["slots"][ctx["next"]]
-    ctx["next"] = (ctx["next"] + 1) % _RING
-    if slot["busy"]:
+    if slot["busy"]:                      # checked BEFORE the ring advances: a refused start leaves the ring where it was
         raise RuntimeError("all_gather_partials_start: more than %d exchanges in flight; collect the oldest first" % _RING)
+    ctx["next"] = (ctx["next"] + 1) % _RING
     slot["busy"] = True
     slot["h_in"].numpy()[:] = src
     with torch.cuda.stream(ctx["stream"]):
@@ -123,6 +131,9 @@ class ShardedMsmResult:
     def result(self):
         return fold_partials(self._group_id, self._gather.result())
 
+    def abandon(self):
+        self._gather.abandon()
+
 
 def sharded_msm_start(group_id, local_partial, device=None, group=None):
     """The pipelined form of sharded_msm: starts the exchange of this rank's partial and returns at once."""
@@ -136,7 +147,12 @@ class ExchangeWorker:
     otherwise sits between a lane finishing and its next submission; here it runs while the submitting thread blocks inside
     zk_msm_collect (ctypes releases the GIL).  All collectives of the loop are issued by this one thread, in post order (the same
     on every rank); flush() returns the last folded result once every exchange handed over has been folded, so nothing is in
-    flight when the caller goes on to a barrier.  An exception in the thread is re-raised by flush()."""
+    flight when the caller goes on to a barrier.
+
+    Errors: an exception in the thread is kept and re-raised by the next flush(); the exchanges in flight at that moment are
+    waited for and their ring slots released, and the posts that follow until that flush() are NOT exchanged -- the other ranks
+    of a collective that this rank no longer joins would block, so a caller treats an error from flush() as fatal for the
+    process group (bench.py exits).  close() ends the thread."""
 
     def __init__(self, group_id, device=None, group=None, cuda_device=None, lag=3):
         import queue
@@ -144,7 +160,10 @@ class ExchangeWorker:
         self._args = (group_id, device, group, cuda_device, lag)
         self.q, self.idle, self.res, self.err = queue.Queue(), threading.Event(), None, None
         self.idle.set()
-        threading.Thread(target=self._run, daemon=True).start()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    _STOP = object()
 
     def _run(self):
         group_id, device, group, cuda_device, lag = self._args
@@ -155,10 +174,12 @@ class ExchangeWorker:
         while True:
             item = self.q.get()
             try:
-                if item is None:                     # flush: finish everything, in order
+                if item is None or item is self._STOP:   # flush / close: finish everything, in order
                     while inflight:
                         self.res = inflight.pop(0).result()
                     self.idle.set()
+                    if item is self._STOP:
+                        return
                     continue
                 if self.err is None:
                     inflight.append(sharded_msm_start(group_id, item, device=device, group=group))
@@ -166,21 +187,37 @@ class ExchangeWorker:
                         self.res = inflight.pop(0).result()
             except BaseException as exc:             # noqa: BLE001 -- handed to the submitting thread by flush()
                 self.err = exc
+                for handle in inflight:              # give their ring slots back (waits for what was enqueued)
+                    try:
+                        handle.abandon()
+                    except BaseException:            # noqa: BLE001
+                        pass
                 inflight.clear()
-                if item is None:
+                if item is None or item is self._STOP:
                     self.idle.set()
+                if item is self._STOP:
+                    return
 
     def post(self, partial):
         self.idle.clear()
         self.q.put(partial)
 
     def flush(self):
+        self.idle.clear()
         self.q.put(None)
         self.idle.wait()
         if self.err is not None:
             err, self.err = self.err, None
             raise err
         return self.res
+
+    def close(self):
+        """Finishes what is in flight and ends the thread (idempotent)."""
+        if self._thread is not None and self._thread.is_alive():
+            self.idle.clear()
+            self.q.put(self._STOP)
+            self._thread.join(timeout=60)
+        self._thread = None
 
 
 # ------------------------------------------------------------------------------------------------

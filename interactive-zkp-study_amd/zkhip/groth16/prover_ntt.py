@@ -161,7 +161,9 @@ class ScaleCRS:
 class ScaleProver:
     """Plans + scratch for proving against one ScaleCRS."""
 
-    def __init__(self, crs):
+    def __init__(self, crs, chunk_log=0):
+        """chunk_log: chunk size of the G1 plan's MSMs beyond it (0 = the library's 2^22); from 2^21 constraints on the merged
+        proof_C query (3 m + 4 bases) runs as chunks in the lanes the A query leaves free."""
         import torch
         self.crs = crs
         c = crs.circuit
@@ -172,7 +174,7 @@ class ScaleProver:
         self.bound = self.m + 2 > (1 << 17)
         self.off14, self.off15 = self.m + 3, self.m + 3 + self.W
         self.n_c = self.off15 + self.m - 1                     # all three queries behind each other: (m+3) + W + (m-1) bases
-        self.g1 = MsmPlan(_lib.GROUP_G1, self.n_c if self.bound else max(self.W, self.m + 3))
+        self.g1 = MsmPlan(_lib.GROUP_G1, self.n_c if self.bound else max(self.W, self.m + 3), chunk_log=chunk_log)
         self.g2 = MsmPlan(_lib.GROUP_G2, self.m + 2)
         if self.bound:
             st0 = torch.cuda.current_stream().cuda_stream

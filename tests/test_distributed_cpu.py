@@ -57,6 +57,11 @@ def _worker(rank, world, port, n, ret):
             pass
         worker.post(xyzz_partial_g1(local))                              # and the worker is usable afterwards
         ok = ok and worker.flush() == got
+        thread = worker._thread
+        worker.post(xyzz_partial_g1(local))                              # close() finishes what is in flight, then ends the thread
+        worker.close()
+        ok = ok and worker.res == got and not thread.is_alive()
+        worker.close()                                                   # idempotent
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -329,19 +329,10 @@ def test_fixed_base_batches_bit_exact(n):
     assert not out1.any()
 
 
-@pytest.fixture
-def chunk_log():
-    """zk_test_set_msm_chunk_log for the plans a test creates; restored to the default afterwards."""
-    lib = _lib.load()
-    yield lambda l: _lib.check(lib.zk_test_set_msm_chunk_log(l))
-    _lib.check(lib.zk_test_set_msm_chunk_log(0))
-
-
-def test_chunked_msm_small_chunks(chunk_log):
+def test_chunked_msm_small_chunks():
     """MSMs beyond the chunk size (2^24 points; here 2^12 through the test knob) run as consecutive chunks in the
     plan's lanes with the partial sums added on the host: blocking, pipelined and partial forms, bit-exact."""
     import torch
-    chunk_log(12)
     rng = np.random.default_rng(31)
     n = 5 * 4096 + 123
     S = rand_fr_limbs(rng, n)
@@ -349,13 +340,27 @@ def test_chunked_msm_small_chunks(chunk_log):
     want = co.g1_msm_bucket_arr(S, Pts, 12)
     dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    plan = MsmPlan(_lib.GROUP_G1, n)
+    plan = MsmPlan(_lib.GROUP_G1, n, chunk_log=12)
     got = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), n, st)[0]
     assert np.array_equal(got, want)
     t = plan.submit(dS.data_ptr(), dP.data_ptr(), n, st)
     with pytest.raises(_lib.ZkhipError):
         plan.submit(dS.data_ptr(), dP.data_ptr(), 100, st)       # nothing else while a chunked MSM is outstanding
     assert np.array_equal(plan.collect_limbs(t)[0], want)
+    # a chunked MSM submitted while earlier submissions are in flight runs in the lanes that are free (a prover's merged query
+    # behind its other queries); the earlier tickets stay collectable in any order
+    want_a, want_b = co.g1_msm_arr(S[:3000], Pts[:3000]), co.g1_msm_arr(S[100:2100], Pts[100:2100])
+    ta = plan.submit(dS.data_ptr(), dP.data_ptr(), 3000, st)
+    tb = plan.submit(dS.data_ptr() + 32 * 100, dP.data_ptr() + 64 * 100, 2000, st)
+    tc = plan.submit(dS.data_ptr(), dP.data_ptr(), n, st)          # one free lane: the chunks take turns in it
+    assert np.array_equal(plan.collect_limbs(ta)[0], want_a)
+    assert np.array_equal(plan.collect_limbs(tc)[0], want)
+    assert np.array_equal(plan.collect_limbs(tb)[0], want_b)
+    t3 = [plan.submit(dS.data_ptr(), dP.data_ptr(), 3000, st) for _ in range(3)]
+    with pytest.raises(_lib.ZkhipError):
+        plan.submit(dS.data_ptr(), dP.data_ptr(), n, st)           # no lane free at all
+    for t in t3:
+        assert np.array_equal(plan.collect_limbs(t)[0], want_a)
     part = plan.run_partial(dS.data_ptr(), dP.data_ptr(), n, st)
     assert np.array_equal(_lib.limbs_to_ints(np.array(co.g1_to_arr([fold_partials(_lib.GROUP_G1, part)]))), _lib.limbs_to_ints(want.reshape(1, 8)))
     small = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), 3000, st)[0]  # below the chunk size: the ordinary path
@@ -420,12 +425,11 @@ def o_point(pt):
 
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
-def test_bound_bases_mode_equals_unbound(group, chunk_log):
+def test_bound_bases_mode_equals_unbound(group):
     """zk_msm_plan_bind_points: the 13-row table of 2^(20 w) * P_i and one window of 2^19 buckets must give the very same
     points as the ordinary 16-window path -- uniform and skewed scalars, prefixes of the bound bases, infinity among the
     bases, three submissions in flight, and a chunked call (test knob) that walks the table with an offset."""
     import torch
-    chunk_log(18)                     # plan workspace for 2^18 points: chunking at testable sizes
     rng = np.random.default_rng(41)
     g2 = group == "g2"
     n = (1 << 18) + 5000 if not g2 else 9000
@@ -447,9 +451,7 @@ def test_bound_bases_mode_equals_unbound(group, chunk_log):
     dP = torch.from_numpy(Pts.view(np.int64)).cuda()
     dS, dW = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(W.view(np.int64)).cuda()
     st = torch.cuda.current_stream().cuda_stream
-    plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, 1 << 18)   # max_n 2^18: n above it only through chunks... use a second plan
-    plan.close()
-    plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, max(n, (1 << 17) + 1))
+    plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, max(n, (1 << 17) + 1), chunk_log=18)   # chunking at testable sizes
     want_s = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), n, st)
     want_w = plan.run_limbs(dW.data_ptr(), dP.data_ptr(), n, st)
     want_pre = plan.run_limbs(dS.data_ptr(), dP.data_ptr(), 5001, st)
@@ -555,9 +557,8 @@ def limbs_to_pt(res):
     return (int(p[0]), int(p[1]))
 
 
-def test_chunked_submission_with_a_bad_chunk_leaves_the_plan_usable(chunk_log):
+def test_chunked_submission_with_a_bad_chunk_leaves_the_plan_usable():
     import torch
-    chunk_log(12)
     rng = np.random.default_rng(256)
     n = 3 * 4096 + 50
     lib = _lib.load()
@@ -567,7 +568,7 @@ def test_chunked_submission_with_a_bad_chunk_leaves_the_plan_usable(chunk_log):
     bad[2 * 4096 + 5] = limb_row((1 << 256) - 1)
     dS, dB, dP = (torch.from_numpy(x.view(np.int64)).cuda() for x in (S, bad, Pts))
     st = torch.cuda.current_stream().cuda_stream
-    plan = MsmPlan(_lib.GROUP_G1, n)
+    plan = MsmPlan(_lib.GROUP_G1, n, chunk_log=12)
     want = co.g1_mul(o.G1, sum(s * (999 + 3 * i) for i, s in enumerate(_lib.limbs_to_ints(S))) % o.R)
     with pytest.raises(_lib.ZkhipError):
         plan.run(dB.data_ptr(), dP.data_ptr(), n, st)

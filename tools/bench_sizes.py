@@ -18,14 +18,13 @@ def main():
     ap.add_argument("--g2", default="")
     ap.add_argument("--ntt", default="16,18,20,22,24")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--chunk-log", type=int, default=0, help="chunk size of MSMs beyond it (zk_test_set_msm_chunk_log; 0 = the library's 2^22)")
+    ap.add_argument("--chunk-log", type=int, default=0, help="chunk size of MSMs beyond it (zk_msm_plan_create_ex; 0 = the library's 2^22)")
     args = ap.parse_args()
     import torch
     from zkhip import _lib
     from zkhip.device import MsmPlan, NttPlan
     from zkhip.field import G1, G2, ec_mul, g2_to_limbs
     lib = _lib.load()
-    _lib.check(lib.zk_test_set_msm_chunk_log(args.chunk_log))
     st = torch.cuda.current_stream().cuda_stream
     out = {"msm_g1": [], "msm_g2": [], "ntt": []}
     for group, sizes in (("g1", args.msm), ("g2", args.g2)):
@@ -38,12 +37,12 @@ def main():
             if big:
                 k0, dd = 0x1234567890ABCDEF >> 1, 0x9E3779B1
                 P = arithmetic_points(lib, n, k0, dd)
-                plan = MsmPlan(_lib.GROUP_G1, n)
+                plan = MsmPlan(_lib.GROUP_G1, n, chunk_log=args.chunk_log)
             elif group == "g1":
                 base = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
                 P = np.zeros((n, 8), dtype=np.uint64)
                 _lib.check(lib.zk_fixed_base_g1(_lib.ptr(base), _lib.ptr(K), n, _lib.ptr(P)))
-                plan = MsmPlan(_lib.GROUP_G1, n)
+                plan = MsmPlan(_lib.GROUP_G1, n, chunk_log=args.chunk_log)
             else:
                 base = g2_to_limbs([G2])
                 P = np.zeros((n, 16), dtype=np.uint64)

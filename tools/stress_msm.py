@@ -35,13 +35,12 @@ def main():
     for it in range(a.iters):
         g2 = rng.random() < 0.25
         chunk = int(rng.choice([0, 12, 14, 18]))
-        _lib.check(_lib.load().zk_test_set_msm_chunk_log(chunk))
         limit = 1 << (chunk or 22)
         cap = n2max if g2 else nmax
         n = int(min(cap, max(1, int(2 ** rng.uniform(0, np.log2(cap))) + int(rng.integers(0, 3)))))
         if not g2 and rng.random() < 0.3:
             n = int(rng.integers((1 << 17) + 1, cap + 1))          # the 16-bit-window / bound-bases range more often
-        plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, n)
+        plan = MsmPlan(_lib.GROUP_G2 if g2 else _lib.GROUP_G1, n, chunk_log=chunk)
         bound = n > (1 << 17) and chunk in (0, 18) and rng.random() < 0.6
         if bound:
             plan.bind((dP2 if g2 else dP1).data_ptr(), n, st)
