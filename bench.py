@@ -93,6 +93,83 @@ def launch_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def host_description():
+    """CPU model and core count of the box the CPU baselines run on (BASELINE.md section 3 asks for both)."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count()}
+
+
+def fit_and_extrapolate(sizes, secs, targets, nlogn):
+    """Least-squares fit of t = a * f(n) through the timed sizes (f = n, or n log2 n for the recursive fft) -> a, the relative
+    residuals and the extrapolated seconds at the target sizes.  SURVEY.md section 8 row D4: 'fitted (linear in n for MSM, n log n for
+    NTT) and extrapolated to the config sizes ... clearly labelled'."""
+    f = lambda n: n * np.log2(n) if nlogn else float(n)
+    x = np.array([f(n) for n in sizes], dtype=np.float64)
+    y = np.array(secs, dtype=np.float64)
+    a = float((x * y).sum() / (x * x).sum())
+    return {"model": "t = a * n * log2(n)" if nlogn else "t = a * n", "a_seconds": a,
+            "measured": [{"n": int(n), "seconds": round(float(t), 4), "fit_seconds": round(a * f(n), 4)} for n, t in zip(sizes, secs)],
+            "max_rel_residual": float(np.max(np.abs(a * x - y) / y)),
+            "extrapolated_seconds": {"2^%d" % L: a * f(1 << L) for L in targets},
+            "label": "reference-shaped pure Python on ONE host core, EXTRAPOLATED from the measured sizes (not measured at these sizes)"}
+
+
+def cpu_baseline_msm(args, plan, scalars, points, d_scalars, d_points, n, stream, result):
+    """The `cpu_baseline` object of the line (row D4): oracle/py_ref.msm_naive -- per-term affine double-and-add + affine add, the
+    reference's zkp/plonk/kzg.py:59-65 -- on one host core at n = 2^6 .. 2^10 plus --cpu-sample points (each equal to the GPU MSM of
+    the same sample), a linear fit extrapolated to 2^20 / 2^24 / 2^26, and the oracle's C Pippenger over the host threads on the
+    full workload.  `result`: the timed GPU result to compare the C line with (None: a fresh GPU run of the same chunk)."""
+    from zkhip import _lib
+    from zkhip.field import limbs_to_g1
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import py_ref
+    import c_oracle
+    k = min(args.cpu_sample, n)
+    sc = _lib.limbs_to_ints(scalars[:k])
+    pts = [(int(p[0]), int(p[1])) for p in limbs_to_g1(points[:k])]
+
+    def timed(m):
+        c0 = time.perf_counter()
+        ref_pt = py_ref.msm_naive(sc[:m], pts[:m])
+        dt = time.perf_counter() - c0
+        sub = plan.run(d_scalars.data_ptr(), d_points.data_ptr(), m, stream)
+        return dt, (sub is None and ref_pt is None) or (sub is not None and ref_pt == (int(sub[0]), int(sub[1])))
+
+    fit_sizes = [m for m in (64, 128, 256, 512, 1024) if m <= k]
+    fit_t, fit_ok = [], True
+    for m in fit_sizes:
+        dt, ok = timed(m)
+        fit_t.append(dt)
+        fit_ok = fit_ok and ok
+    cdt, same = timed(k)
+    fit = fit_and_extrapolate(fit_sizes + [k], fit_t + [cdt], (20, 24, 26), False) if fit_sizes else None
+    if fit:
+        fit["every_sample_equals_gpu"] = bool(fit_ok and same)
+    # second CPU line ("strong CPU"): the oracle's bucket-method MSM in C with its windows spread over the host threads
+    threads = max(1, min(16, os.cpu_count() or 1))
+    c1 = time.perf_counter()
+    c_pt = c_oracle.g1_msm_bucket_mt_arr(scalars, points, 16, threads)
+    cct = time.perf_counter() - c1
+    if result is None:
+        result = plan.run_limbs(d_scalars.data_ptr(), d_points.data_ptr(), n, stream)
+    same_c = bool((not result[1]) and np.array_equal(result[0], c_pt))
+    compiled = {"value": n / cct, "unit": "points/s", "cores": threads, "kind": "port",
+                "sample": "all %d points of rank 0's workload, oracle/bn254_oracle.c orc_g1_msm_bucket_mt (Pippenger, c=16, Jacobian, windows over %d "
+                          "threads); %.1f s; bit-identical to the GPU result for the same points: %s" % (n, threads, cct, same_c)}
+    return {"value": k / cdt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": "first %d points/scalars of the same workload, oracle/py_ref.msm_naive "
+                      "(affine double-and-add per term, as zkp/plonk/kzg.py:59-65); %.1f s; matches GPU MSM of the same sample: %s"
+                      % (k, cdt, same),
+            "host": host_description(), "extrapolation": fit, "compiled_c": compiled}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -390,21 +467,30 @@ def main():
             agg = world * 2 * reps * m / span   # wall clock between barriers (includes launch latency), all ranks
             extra["ntt"]["all_gpus"] = {"mode": "one polynomial per GPU, no exchange", "elements_per_s": agg,
                                         "hbm_frac_per_gpu": 64.0 * agg / world / 1e9 / HBM_PEAK_GBS}
-        if rank == 0 and world == 1 and args.cpu_sample:
-            # CPU lines beside the NTT (row D4): the reference-shaped recursive fft (polynomial.py:292-341) in pure Python on the
-            # first 2^16 coefficients, and the C oracle's iterative NTT on the whole vector -- each compared with the GPU output
+        if rank == 0 and args.cpu_sample:
+            # CPU lines beside the NTT (row D4): the reference-shaped recursive fft (polynomial.py:292-341) in pure Python on prefixes
+            # of 2^8 .. 2^14 and 2^16 coefficients (n log n fit, extrapolated to the config sizes), and the C oracle's iterative NTT on
+            # the whole vector -- each compared with the GPU output
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import py_ref
             import c_oracle
-            Ls = min(16, L)
-            ms_ = 1 << Ls
-            small = torch.from_numpy(coeffs[:ms_].copy().view(np.int64)).to(dev)
-            NttPlan(Ls).run(small.data_ptr(), False, None, stream)
-            torch.cuda.synchronize()
-            p0 = time.perf_counter()
-            py_out = py_ref.fft(_lib.limbs_to_ints(coeffs[:ms_]), py_ref.get_root_of_unity(ms_))
-            pdt = time.perf_counter() - p0
-            same_py = _lib.limbs_to_ints(small.cpu().numpy().view(np.uint64).reshape(-1, 4)) == [int(v) for v in py_out]
+            fit_n, fit_t, all_same = [], [], True
+            for Ls in [v for v in (8, 10, 12, 14, 16) if v <= L]:
+                ms_ = 1 << Ls
+                small = torch.from_numpy(coeffs[:ms_].copy().view(np.int64)).to(dev)
+                NttPlan(Ls).run(small.data_ptr(), False, None, stream)
+                torch.cuda.synchronize()
+                ints = _lib.limbs_to_ints(coeffs[:ms_])
+                w_s = py_ref.get_root_of_unity(ms_)
+                p0 = time.perf_counter()
+                py_out = py_ref.fft(ints, w_s)
+                pdt = time.perf_counter() - p0
+                same_py = _lib.limbs_to_ints(small.cpu().numpy().view(np.uint64).reshape(-1, 4)) == [int(v) for v in py_out]
+                all_same = all_same and same_py
+                fit_n.append(ms_)
+                fit_t.append(pdt)
+            nfit = fit_and_extrapolate(fit_n, fit_t, (22, 24), True)
+            nfit["every_sample_equals_gpu"] = bool(all_same)
             nplan.run(d.data_ptr(), False, None, stream)
             torch.cuda.synchronize()
             gpu_fwd = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
@@ -416,6 +502,7 @@ def main():
                 "value": ms_ / pdt, "unit": "elements/s", "cores": 1, "kind": "port",
                 "sample": "first 2^%d coefficients, oracle/py_ref.fft (recursive radix-2, as zkp/plonk/polynomial.py:292-341); %.2f s; "
                           "equals the GPU transform of the same sample: %s" % (Ls, pdt, same_py),
+                "host": host_description(), "extrapolation": nfit,
                 "compiled_c": {"value": m / cdt_, "unit": "elements/s", "cores": 1, "kind": "port",
                                "sample": "all 2^%d coefficients, oracle/bn254_oracle.c orc_ntt; %.2f s; bit-identical to the GPU forward transform: %s"
                                          % (L, cdt_, bool(np.array_equal(gpu_fwd, c_out)))}}
@@ -578,36 +665,11 @@ def main():
         except Exception as exc:
             extra["plonk_prove"] = {"error": repr(exc)}
 
-    # ---- CPU baseline: reference-shaped pure-Python path on a bounded sample (rank 0, N = 1 only)
+    # ---- CPU baseline: reference-shaped pure-Python path on a bounded sample, on rank 0's host cores (for N > 1 the sample and the
+    # C line are rank 0's chunk of the workload; the other ranks wait at the closing barrier)
     cpu = None
-    if args.cpu_sample and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import py_ref
-        k = min(args.cpu_sample, n)
-        sc = _lib.limbs_to_ints(scalars[:k])
-        pts = [(int(p[0]), int(p[1])) for p in limbs_to_g1(points[:k])]
-        c0 = time.perf_counter()
-        ref_pt = py_ref.msm_naive(sc, pts)
-        cdt = time.perf_counter() - c0
-        sub = plan.run(d_scalars.data_ptr(), d_points.data_ptr(), k, stream)
-        same = (sub is None and ref_pt is None) or (sub is not None and ref_pt == (int(sub[0]), int(sub[1])))
-        # second CPU line ("strong CPU"): the oracle's bucket-method MSM in C with its windows
-        # spread over the host threads a one-GPU box offers, on the FULL workload
-        import c_oracle
-        threads = max(1, min(16, os.cpu_count() or 1))
-        c1 = time.perf_counter()
-        c_pt = c_oracle.g1_msm_bucket_mt_arr(scalars, points, 16, threads)
-        cct = time.perf_counter() - c1
-        same_c = (not result[1]) and np.array_equal(result[0], c_pt) if not dist_on else None
-        compiled = {"value": n / cct, "unit": "points/s", "cores": threads, "kind": "port",
-                    "sample": "all %d points, oracle/bn254_oracle.c orc_g1_msm_bucket_mt (Pippenger, c=16, Jacobian, windows over %d threads); "
-                              "%.1f s; bit-identical to the GPU result of the timed steps: %s" % (n, threads, cct, same_c)}
-        cpu = {"value": k / cdt, "unit": "points/s", "cores": 1, "kind": "port",
-               "sample": "first %d points/scalars of the same workload, oracle/py_ref.msm_naive "
-                         "(affine double-and-add per term, as zkp/plonk/kzg.py:59-65); %.1f s; matches GPU MSM of the same sample: %s"
-                         % (k, cdt, same),
-               "compiled_c": compiled}
-
+    if args.cpu_sample and rank == 0:
+        cpu = cpu_baseline_msm(args, plan, scalars, points, d_scalars, d_points, n, stream, None if dist_on else result)
     if rank == 0:
         total_points = n * world * args.steps
         acc_ms = float(stage[2])

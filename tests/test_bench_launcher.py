@@ -92,3 +92,33 @@ def test_committed_issue_rate_reads_the_profile_or_returns_none(tmp_path):
         assert mod.committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >") is None
     finally:
         mod.ROOT = root
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_python_baseline_fit_and_labelled_extrapolation():
+    """Row D4: the pure-Python baseline is timed at small sizes, fitted (linear for the MSM, n log n for the fft) and extrapolated
+    to the config sizes, labelled as extrapolated; the host's CPU model / nproc travel with it."""
+    mod = _load_bench()
+    sizes = [64, 128, 256, 512, 1024]
+    lin = mod.fit_and_extrapolate(sizes, [3.1e-3 * n for n in sizes], (20, 24, 26), False)
+    assert abs(lin["a_seconds"] - 3.1e-3) < 1e-12 and lin["max_rel_residual"] < 1e-9
+    assert abs(lin["extrapolated_seconds"]["2^20"] - 3.1e-3 * (1 << 20)) < 1e-6
+    assert set(lin["extrapolated_seconds"]) == {"2^20", "2^24", "2^26"} and "EXTRAPOLATED" in lin["label"]
+    nl = mod.fit_and_extrapolate([256, 1024, 4096], [2e-6 * n * np.log2(n) for n in (256, 1024, 4096)], (22, 24), True)
+    assert abs(nl["extrapolated_seconds"]["2^22"] - 2e-6 * (1 << 22) * 22) < 1e-6 and "log2" in nl["model"]
+    noisy = mod.fit_and_extrapolate(sizes, [3e-3 * n * (1.1 if i % 2 else 0.9) for i, n in enumerate(sizes)], (20,), False)
+    assert 0.05 < noisy["max_rel_residual"] < 0.2
+    host = mod.host_description()
+    assert host["nproc"] == os.cpu_count() and (host["cpu_model"] is None or isinstance(host["cpu_model"], str))
