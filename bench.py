@@ -656,6 +656,16 @@ def main():
         except Exception as exc:  # the headline number must not depend on the secondary measurement
             extra["groth16_prove"] = {"error": repr(exc)}
 
+    # ---- secondary: the reference-signature facade at the reference's own sizes (BASELINE.json configs[0]: toy Groth16 / PLONK proofs
+    # through the host-buffer ABI, one library call per primitive; the entry points keep their plans)
+    if rank == 0 and world == 1 and not dist_on:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_facade
+            extra["facade_toy_ms"] = bench_facade.run(5)
+        except Exception as exc:  # noqa: BLE001
+            extra["facade_toy_ms"] = {"error": repr(exc)}
+
     # ---- secondary: PLONK prove() on a synthetic 2^20-gate circuit, all vectors resident in HBM
     if args.plonk_log_n and world == 1:
         try:

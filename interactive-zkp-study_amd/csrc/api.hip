@@ -267,47 +267,96 @@ template <class F> static int group_op_host(int op, const uint64_t *p, const uin
     return ZK_OK;
 }
 
-// Host-buffer MSM.  Small calls (the facade's toy-size proofs, verifier combinations) reuse one cached
-// plan per group and thread instead of allocating a workspace per call.
+// ------------------------------------------------------------------ plan caches behind the host-buffer entry points
+// zk_msm_g1 / zk_msm_g2 / zk_ntt_fr are what the reference-signature facade calls (commit, proof_a/b/c, fft / ifft): one call per
+// primitive, host buffers in and out.  Building a plan per call cost milliseconds (NTT: host power tables, uploads, a device
+// synchronisation; MSM: workspace allocation) -- more than the transform of a toy-sized proof.  Plans are therefore kept per
+// thread and device: NTT plans by log_n, MSM plans by group and size class (next power of two), a few of each (least recently
+// used goes first), together with their staging buffers.  zk_cache_clear() drops the calling thread's; zk_cache_stats() counts.
+struct CacheStats {
+    uint64_t ntt_builds = 0, ntt_hits = 0, msm_builds = 0, msm_hits = 0;
+};
+static thread_local CacheStats g_cache_stats;
+struct HostMsmCtx {
+    std::unique_ptr<MsmPlanBase> plan;
+    DevBuf in;
+    size_t cls = 0;
+    uint64_t used = 0;
+};
+struct HostNttCtx {
+    std::unique_ptr<NttPlan> plan;
+    DevBuf buf;
+    uint64_t used = 0;
+};
+static thread_local std::map<std::pair<int, int>, std::vector<std::unique_ptr<HostMsmCtx>>> g_msm_cache;   // (device, group)
+static thread_local std::map<std::pair<int, unsigned>, std::unique_ptr<HostNttCtx>> g_ntt_cache;            // (device, log_n)
+static thread_local uint64_t g_cache_clock = 0;
+constexpr size_t MSM_CACHE_PER_GROUP = 3, NTT_CACHE_PLANS = 6;
+
+static HostMsmCtx &host_msm_ctx(int group, size_t n, size_t point_bytes) {
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    size_t cls = 4096;                       // the facade's toy-size proofs and verifier combinations share the smallest class
+    while (cls < n) cls <<= 1;
+    auto &slots = g_msm_cache[std::make_pair(dev, group)];
+    for (auto &c : slots)
+        if (c->cls == cls) {
+            g_cache_stats.msm_hits++;
+            c->used = ++g_cache_clock;
+            return *c;
+        }
+    if (slots.size() >= MSM_CACHE_PER_GROUP) {
+        size_t lru = 0;
+        for (size_t i = 1; i < slots.size(); i++)
+            if (slots[i]->used < slots[lru]->used) lru = i;
+        slots.erase(slots.begin() + lru);
+    }
+    std::unique_ptr<HostMsmCtx> c(new HostMsmCtx);
+    c->cls = cls;
+    c->plan.reset(msm_plan_new(group, cls));
+    c->in.alloc(cls * (32 + point_bytes));
+    c->used = ++g_cache_clock;
+    g_cache_stats.msm_builds++;
+    slots.push_back(std::move(c));
+    return *slots.back();
+}
+static HostNttCtx &host_ntt_ctx(unsigned log_n) {
+    int dev = 0;
+    ZK_HIP(hipGetDevice(&dev));
+    auto it = g_ntt_cache.find(std::make_pair(dev, log_n));
+    if (it != g_ntt_cache.end()) {
+        g_cache_stats.ntt_hits++;
+        it->second->used = ++g_cache_clock;
+        return *it->second;
+    }
+    if (g_ntt_cache.size() >= NTT_CACHE_PLANS) {
+        auto lru = g_ntt_cache.begin();
+        for (auto j = g_ntt_cache.begin(); j != g_ntt_cache.end(); ++j)
+            if (j->second->used < lru->second->used) lru = j;
+        g_ntt_cache.erase(lru);
+    }
+    std::unique_ptr<HostNttCtx> c(new HostNttCtx);
+    c->plan.reset(new NttPlan(log_n));
+    c->buf.alloc(((size_t)1 << log_n) * 32);
+    c->used = ++g_cache_clock;
+    g_cache_stats.ntt_builds++;
+    return *(g_ntt_cache[std::make_pair(dev, log_n)] = std::move(c));
+}
+
+// Host-buffer MSM (cached plan of the size class, see above).
 template <class F> static int msm_host(int group, const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t *out_xy, int *out_is_inf) {
     constexpr size_t PB = 8 * F::CANON_WORDS;
-    constexpr size_t SMALL = 4096;
     if (n == 0) {
         memset(out_xy, 0, PB);
         if (out_is_inf) *out_is_inf = 1;
         return ZK_OK;
     }
     if (!scalars_canonical(scalars, n)) return invalid("zk_msm: scalar not canonical (>= r)");
-    // cached per (device, group): a plan's buffers and streams live on the device that was current when it was made
-    struct SmallCtx {
-        std::unique_ptr<MsmPlanBase> plan;
-        DevBuf in;
-    };
-    static thread_local std::map<std::pair<int, int>, std::unique_ptr<SmallCtx>> small;
-    std::unique_ptr<MsmPlanBase> big_plan;
-    MsmPlanBase *plan;
-    DevBuf big_in, *in;
-    if (n <= SMALL) {
-        int dev = 0;
-        ZK_HIP(hipGetDevice(&dev));
-        std::unique_ptr<SmallCtx> &ctx = small[std::make_pair(dev, group)];
-        if (!ctx) {
-            ctx.reset(new SmallCtx);
-            ctx->plan.reset(msm_plan_new(group, SMALL));
-            ctx->in.alloc(SMALL * (32 + PB));
-        }
-        plan = ctx->plan.get();
-        in = &ctx->in;
-    } else {
-        big_plan.reset(msm_plan_new(group, n));
-        big_in.alloc(n * (32 + PB));
-        plan = big_plan.get();
-        in = &big_in;
-    }
-    char *ds = in->as<char>(), *dp = ds + n * 32;
+    HostMsmCtx &ctx = host_msm_ctx(group, n, PB);
+    char *ds = ctx.in.as<char>(), *dp = ds + n * 32;
     ZK_HIP(hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice));
     ZK_HIP(hipMemcpy(dp, points, n * PB, hipMemcpyHostToDevice));
-    return plan->run_affine(ds, dp, n, out_xy, out_is_inf, 0);
+    return ctx.plan->run_affine(ds, dp, n, out_xy, out_is_inf, 0);
 }
 
 template <class F> static int fold_partials(const uint64_t *partials, size_t count, uint64_t *out_xy, int *out_is_inf) {
@@ -573,14 +622,28 @@ int zk_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t coset_
         const size_t n = (size_t)1 << log_n;
         if (!scalars_canonical(data, n)) return invalid("zk_ntt_fr: element not canonical (>= r)");
         if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_fr: coset_shift must be a canonical non-zero element of F_r");
-        NttPlan plan(log_n);
-        DevBuf d(n * 32);
-        ZK_HIP(hipMemcpy(d.p, data, n * 32, hipMemcpyHostToDevice));
-        plan.run(d.p, inverse != 0, coset_shift, 0);
-        ZK_HIP(hipDeviceSynchronize());
-        ZK_HIP(hipMemcpy(data, d.p, n * 32, hipMemcpyDeviceToHost));
+        HostNttCtx &ctx = host_ntt_ctx(log_n);   // plan (tables) + staging buffer of this size, built once per thread and device
+        ZK_HIP(hipMemcpy(ctx.buf.p, data, n * 32, hipMemcpyHostToDevice));
+        ctx.plan->run(ctx.buf.p, inverse != 0, coset_shift, 0);
+        ZK_HIP(hipStreamSynchronize(0));
+        ZK_HIP(hipMemcpy(data, ctx.buf.p, n * 32, hipMemcpyDeviceToHost));
         return ZK_OK;
     });
+}
+int zk_cache_clear(void) {
+    return guarded([&] {
+        g_msm_cache.clear();
+        g_ntt_cache.clear();
+        return ZK_OK;
+    });
+}
+int zk_cache_stats(uint64_t out[4]) {
+    if (!out) return invalid("zk_cache_stats: null pointer");
+    out[0] = g_cache_stats.ntt_builds;
+    out[1] = g_cache_stats.ntt_hits;
+    out[2] = g_cache_stats.msm_builds;
+    out[3] = g_cache_stats.msm_hits;
+    return ZK_OK;
 }
 int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals, const void *d_x, void *d_y, size_t rows, void *stream) {
     return guarded([&] {

@@ -57,6 +57,8 @@ _PROTOS = {
     "zk_msm_fold_partials": (ctypes.c_int, [ctypes.c_int, _VP, _SZ, _VP, ctypes.POINTER(ctypes.c_int)]),
     "zk_msm_partial_limbs": (ctypes.c_int, [ctypes.c_int]),
     "zk_ntt_fr": (ctypes.c_int, [_VP, ctypes.c_uint, ctypes.c_int, _VP]),
+    "zk_cache_clear": (ctypes.c_int, []),
+    "zk_cache_stats": (ctypes.c_int, [_VP]),
     "zk_ntt_plan_create": (ctypes.c_int, [ctypes.c_uint, ctypes.POINTER(_VP)]),
     "zk_ntt_plan_destroy": (ctypes.c_int, [_VP]),
     "zk_ntt_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_int, _VP, _VP]),
@@ -108,6 +110,13 @@ def load():
 def check(rc):
     if rc != ZK_OK:
         raise ZkhipError(rc, load().zk_last_error().decode("utf-8", "replace"))
+
+
+def cache_stats():
+    """{ntt_builds, ntt_hits, msm_builds, msm_hits} of the host-buffer plan cache (zk_cache_stats; calling thread)."""
+    out = np.zeros(4, dtype=np.uint64)
+    check(load().zk_cache_stats(ptr(out)))
+    return dict(zip(("ntt_builds", "ntt_hits", "msm_builds", "msm_hits"), (int(v) for v in out)))
 
 
 def device_count():

@@ -349,3 +349,46 @@ def test_kzg_openings(srs_small):
         assert verify_opening(C, pi, z + FR(1), y, srs_small) is False          # wrong point
     const = Polynomial([FR(9)])
     assert verify_opening(commit(const, srs_small), create_witness(const, FR(5), srs_small), FR(5), FR(9), srs_small)
+
+
+def test_host_buffer_entry_points_reuse_their_plans(srs_small):
+    """fft / ifft / commit go through zk_ntt_fr / zk_msm_g1 once per call: the NTT tables of a size and the MSM workspace of a size
+    class are built by the FIRST call only (zk_cache_stats), a different size builds its own, and zk_cache_clear starts over."""
+    import numpy as np
+    from zkhip import _lib
+    lib = _lib.load()
+    _lib.check(lib.zk_cache_clear())
+    s0 = _lib.cache_stats()
+    omega = get_root_of_unity(8)
+    vals = [FR(3 * i + 1) for i in range(8)]
+    want = fft(vals, omega)
+    s1 = _lib.cache_stats()
+    assert s1["ntt_builds"] == s0["ntt_builds"] + 1
+    for _ in range(3):
+        assert fft(vals, omega) == want and ifft(want, omega) == vals
+    s2 = _lib.cache_stats()
+    assert s2["ntt_builds"] == s1["ntt_builds"] and s2["ntt_hits"] == s1["ntt_hits"] + 6
+    fft([FR(i) for i in range(16)], get_root_of_unity(16))                  # another size: one more plan
+    assert _lib.cache_stats()["ntt_builds"] == s2["ntt_builds"] + 1
+    p = Polynomial([FR(1), FR(2), FR(3)])
+    c0 = commit(p, srs_small)
+    m1 = _lib.cache_stats()
+    c1 = commit(p, srs_small)
+    m2 = _lib.cache_stats()
+    assert c0 == c1 and m2["msm_builds"] == m1["msm_builds"] and m2["msm_hits"] == m1["msm_hits"] + 1
+    # a size class of its own (> 4096 points), twice: one build
+    n = 5000
+    S = _lib.ints_to_limbs([(i * 7919 + 1) % CURVE_ORDER for i in range(n)])
+    K = _lib.ints_to_limbs([i + 1 for i in range(n)])
+    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+    P = np.zeros((n, 8), dtype=np.uint64)
+    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(K), n, _lib.ptr(P)))
+    out, inf = np.zeros(8, dtype=np.uint64), __import__("ctypes").c_int(0)
+    b0 = _lib.cache_stats()["msm_builds"]
+    for _ in range(2):
+        _lib.check(lib.zk_msm_g1(_lib.ptr(S), _lib.ptr(P), n, _lib.ptr(out), __import__("ctypes").byref(inf)))
+    assert _lib.cache_stats()["msm_builds"] == b0 + 1
+    assert _lib.limbs_to_ints(out.reshape(2, 4)) == [int(v) for v in ec_mul(G1, sum((i * 7919 + 1) * (i + 1) for i in range(n)) % CURVE_ORDER)]
+    _lib.check(lib.zk_cache_clear())
+    assert fft(vals, omega) == want                                          # rebuilt after the clear
+    assert _lib.cache_stats()["ntt_builds"] == s2["ntt_builds"] + 2
