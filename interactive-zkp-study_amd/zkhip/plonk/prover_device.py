@@ -190,6 +190,93 @@ class DevicePlonk:
         self._lin(coef[n:n + k], [coef[n:n + k], bl], [1, 1], k)
         return coef
 
+    # ---- grand product -------------------------------------------------------------------------------------------
+    def _accumulator(self, cols, be, ga):
+        """z on the domain (permutation.py:89-137): z_0 = 1, z_{i+1} = z_i * num_i / den_i, as prefix products of the numerators
+        times suffix products of the denominators over their total -- ONE inversion.  The reference divides row by row with
+        inv0(0) = 0, so a zero denominator zeroes z from that row on and leaves the rows before it; a zero TOTAL (probability
+        about n / r for Fiat-Shamir challenges; it also covers row n - 1, which the reference never divides by) cannot be
+        inverted here, and that case takes the row-exact host path (_accumulator_exact), so z equals the reference's always."""
+        n, fv, st = self.n, self.fv, self.st
+        num, den = self._accumulator_factors(cols, be, ga)
+        fv.scan(num.data_ptr(), n, True, False, st)                              # prod_{j<=i} num_j
+        fv.scan(den.data_ptr(), n, True, True, st)                               # prod_{j>=i} den_j
+        den_total = _lib.limbs_to_ints(den[:1].cpu().numpy().view(np.uint64))[0]
+        if den_total == 0:
+            return self._accumulator_exact(*self._accumulator_factors(cols, be, ga))   # the scans ran in place: rebuild the factors
+        z_ev = self.buf["z_ev"][:n]
+        z_ev[:1] = self.ones[:1]
+        self._mul(z_ev[1:], num[:n - 1], den[1:], n - 1)                         # z_i = prod_{j<i} num_j / den_j
+        self._lin(z_ev[1:], [z_ev[1:]], [pow(den_total, -1, R)], n - 1)
+        return z_ev
+
+    def _accumulator_factors(self, cols, be, ga):
+        """Per row: num_i = prod_w (w_i + beta * k_w * omega^i + gamma), den_i = prod_w (w_i + beta * sigma_w(i) + gamma)."""
+        n, B = self.n, self.buf
+        num, den, tmp = B["num"][:n], B["den"][:n], B["tmp"][:n]
+        sig = [self.evals["s_sigma%d" % k] for k in (1, 2, 3)]
+        for j, (col, idc) in enumerate(zip(cols, (1, int(K1), int(K2)))):
+            self._lin(tmp, [col, self.ident], [1, be * idc % R], n, ga)          # w + beta * k * omega^i + gamma
+            if j == 0:
+                num.copy_(tmp)
+            else:
+                self._mul(num, num, tmp, n)
+            self._lin(tmp, [col, sig[j]], [1, be], n, ga)                        # w + beta * sigma(i) + gamma
+            if j == 0:
+                den.copy_(tmp)
+            else:
+                self._mul(den, den, tmp, n)
+        return num, den
+
+    def _accumulator_exact(self, num, den):
+        """The reference's loop on the host, from the per-row numerators / denominators: z_{i+1} = z_i * num_i * inv0(den_i)
+        with inv0(0) = 0 (py_ecc's FQ division); one batch inversion over the non-zero denominators."""
+        n = self.n
+        nums = _lib.limbs_to_ints(num.cpu().numpy().view(np.uint64))
+        dens = _lib.limbs_to_ints(den.cpu().numpy().view(np.uint64))
+        pref = [1]
+        for d in dens[:n - 1]:
+            pref.append(pref[-1] * (d or 1) % R)
+        inv = pow(pref[-1], -1, R)
+        inv_d = [0] * (n - 1)
+        for i in range(n - 2, -1, -1):
+            inv_d[i] = pref[i] * inv % R if dens[i] else 0
+            inv = inv * (dens[i] or 1) % R
+        z = [1]
+        for i in range(n - 1):
+            z.append(z[-1] * nums[i] % R * inv_d[i] % R)
+        z_ev = self.buf["z_ev"][:n]
+        z_ev.copy_(_dev(_limbs(z)))
+        return z_ev
+
+    # ---- independent check of the commitments --------------------------------------------------------------------
+    def committed_polynomials(self):
+        """[(proof field, coefficient buffer, count)] of the LAST proof's nine commitments plus the eight of the preprocessing:
+        with a known tau every one of them must equal p(tau) * G1 (tests, tools/bench_plonk.py)."""
+        n, B = self.n, self.buf
+        out = [("a_comm", B["w0"], n + 2), ("b_comm", B["w1"], n + 2), ("c_comm", B["w2"], n + 2), ("z_comm", B["z"], n + 3),
+               ("t_lo_comm", B["t0"], n), ("t_mid_comm", B["t1"], n), ("t_hi_comm", B["t2"], n + 6),
+               ("W_zeta_comm", B["q0"], n + 5), ("W_zeta_omega_comm", B["q1"], n + 2)]
+        return out + [(k + "_comm", self.coef[k], n) for k in ("q_l", "q_r", "q_o", "q_m", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")]
+
+    def closed_form_mismatches(self, proof, tau, on_host=False):
+        """Names of the commitments that differ from p(tau) * G1.  p(tau) comes from the device (scale by the powers of tau,
+        running sum: zk_fr_scale_powers_dev + zk_fr_scan_dev) or, on_host, from Horner's rule on Python integers over the
+        downloaded coefficients -- no MSM, no SRS point involved either way."""
+        from ..field import G1, ec_mul
+        bad = []
+        for name, coef, count in self.committed_polynomials():
+            if on_host:
+                val = 0
+                for cv in reversed(_lib.limbs_to_ints(coef[:count].cpu().numpy().view(np.uint64))):
+                    val = (val * tau + cv) % R
+            else:
+                val = int(self._evaluate(coef, count, tau))
+            have = self.comm[name[:-5]] if name[:-5] in self.comm else getattr(proof, name)   # preprocessing / proof field
+            if have != ec_mul(G1, val):
+                bad.append(name)
+        return bad
+
     # ---- interface to the verifier ---------------------------------------------------------------------------
     def preprocessed(self):
         """Object with the fields zkhip.plonk.verifier.verify reads (preprocessor.py:59-130)."""
@@ -227,26 +314,7 @@ class DevicePlonk:
         # round 2 (round2.py:50-86, permutation.py:89-137)
         beta, gamma = tr.challenge_scalar(b"beta"), tr.challenge_scalar(b"gamma")
         be, ga = int(beta), int(gamma)
-        num, den, tmp = B["num"][:n], B["den"][:n], B["tmp"][:n]
-        sig = [self.evals["s_sigma%d" % k] for k in (1, 2, 3)]
-        for j, (col, idc) in enumerate(zip(cols, (1, k1, k2))):
-            self._lin(tmp, [col, self.ident], [1, be * idc % R], n, ga)          # w + beta * k * omega^i + gamma
-            if j == 0:
-                num.copy_(tmp)
-            else:
-                self._mul(num, num, tmp, n)
-            self._lin(tmp, [col, sig[j]], [1, be], n, ga)                        # w + beta * sigma(i) + gamma
-            if j == 0:
-                den.copy_(tmp)
-            else:
-                self._mul(den, den, tmp, n)
-        fv.scan(num.data_ptr(), n, True, False, st)                              # prod_{j<=i} num_j
-        fv.scan(den.data_ptr(), n, True, True, st)                               # prod_{j>=i} den_j
-        den_total = _lib.limbs_to_ints(den[:1].cpu().numpy().view(np.uint64))[0]
-        z_ev = B["z_ev"][:n]
-        z_ev[:1] = self.ones[:1]
-        self._mul(z_ev[1:], num[:n - 1], den[1:], n - 1)                         # z_i = prod_{j<i} num_j / den_j
-        self._lin(z_ev[1:], [z_ev[1:]], [pow(den_total, -1, R)], n - 1)
+        z_ev = self._accumulator(cols, be, ga)
         z = self._blinded(self._interpolate(z_ev, B["z"]), blind[6:9])
         t_z = self._submit(z, n + 3)
         ez = self._coset(z, self.work[3])                    # likewise under the commitment of z

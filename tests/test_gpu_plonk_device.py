@@ -117,6 +117,13 @@ def test_device_prover_2pow12_verifies_and_rejects_tampering():
     proof = dev.prove(_limbs(a), _limbs(b), _limbs(c))
     pp = dev.preprocessed()
     assert verify(proof, [], pp, Srs)
+    # independent of this repo's verifier: tau is known, so every commitment must be p(tau) * G1 -- Horner on Python integers over
+    # the downloaded coefficients, and the device's own scale-and-sum evaluation, against one scalar multiplication each
+    assert dev.closed_form_mismatches(proof, tau, on_host=True) == []
+    assert dev.closed_form_mismatches(proof, tau) == []
+    wrong = copy.copy(proof)
+    wrong.t_hi_comm = proof.t_mid_comm
+    assert dev.closed_form_mismatches(wrong, tau) == ["t_hi_comm"]
     bad = copy.copy(proof)
     bad.a_eval = proof.a_eval + FR(1)
     assert not verify(bad, [], pp, Srs)
@@ -127,3 +134,36 @@ def test_device_prover_2pow12_verifies_and_rejects_tampering():
     c_bad[100] = (c_bad[100] + 1) % R                                   # unsatisfied gate: t is not a polynomial
     with pytest.raises(ValueError):
         dev.prove(_limbs(a), _limbs(b), _limbs(c_bad))
+
+
+@pytest.mark.parametrize("zero_row", [0, 5, 15])
+def test_device_grand_product_with_a_zero_denominator_equals_the_reference_loop(zero_row):
+    """permutation.py:118-135 divides row by row and py_ecc's x / 0 is 0: a zero denominator zeroes z from the NEXT row on and keeps
+    the rows before it.  The device computes z with scans and ONE inversion of the denominators' total; a zero total (which also
+    covers the last row, that the reference never divides by) is detected and takes the row-exact path.  Challenges are chosen so
+    that row `zero_row` has a zero denominator; z must equal the oracle's loop (oracle/plonk_ref.compute_accumulator) and the
+    list prover's compute_accumulator."""
+    import plonk_ref as pl
+    from zkhip.plonk.permutation import compute_accumulator
+    circuit, a, b, c = _chain_circuit(16, 9)
+    srs = SRS.generate(16 + 80, seed=42)
+    pp = preprocess(circuit, srs)
+    n = pp.n
+    assert n == 16
+    dev = _device_from_circuit(circuit, pp, srs)
+    s1, s2, s3 = build_permutation_polynomials(pp.sigma, n, pp.domain)
+    beta = 0x1234567
+    gamma = (-(int(a[zero_row]) + beta * int(s1[zero_row]))) % R          # a_i + beta * sigma_1(i) + gamma = 0
+    want = pl.compute_accumulator([int(v) for v in a], [int(v) for v in b], [int(v) for v in c], list(pp.sigma), n, [int(d) for d in pp.domain], beta, gamma)
+    if zero_row < n - 1:
+        assert all(v == 0 for v in want[zero_row + 1:]) and all(v != 0 for v in want[:zero_row + 1])
+    else:
+        assert all(v != 0 for v in want)                                  # the last row's denominator never enters z
+    assert [int(v) for v in compute_accumulator(a, b, c, pp.sigma, n, pp.domain, FR(beta), FR(gamma))] == want
+    import torch
+    cols = [torch.from_numpy(_limbs(col).view(np.int64)).cuda() for col in (a, b, c)]
+    got = dev._accumulator(cols, beta, gamma)
+    assert _lib.limbs_to_ints(got.cpu().numpy().view(np.uint64)) == want
+    # and with ordinary challenges the scan path gives the same z as the loop
+    want2 = pl.compute_accumulator([int(v) for v in a], [int(v) for v in b], [int(v) for v in c], list(pp.sigma), n, [int(d) for d in pp.domain], 77, 99)
+    assert _lib.limbs_to_ints(dev._accumulator(cols, 77, 99).cpu().numpy().view(np.uint64)) == want2
