@@ -157,6 +157,23 @@ int zk_ntt_plan_destroy(zk_ntt_plan *plan);
 int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t coset_shift[4], void *stream);
 /* `batch` independent transforms of the plan's size stored back to back in d_data (no coset shift). */
 int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream);
+/* Batched transform between two DEVICE buffers whose layouts are those of the four-step (multi-GPU) transform, so that the
+ * per-destination pack, the transpose after the exchange and the twiddle between the two dimensions happen inside the first
+ * pass's loads and the last pass's stores instead of in passes of their own.  Element i of
+ * transform b (of `batch`) sits at
+ *   ZK_NTT_PLAIN       b * n + i                                          transforms back to back;
+ *   ZK_NTT_BLOCKED_TW  (((i >> log_block) * batch + b) << log_block) | (i mod 2^log_block), and the value read / written is
+ *                      multiplied by w_N^(+-(row0 + b) * i), N = size of `big` (tw_inverse != 0: the inverse root): the buffer an
+ *                      all-to-all sends / has received, block s of it belonging to rank s;
+ *   ZK_NTT_TRANSPOSED  i * batch + b                                      the matrix transpose (element-major).
+ * At most one side may be ZK_NTT_BLOCKED_TW; d_out may equal d_in only when both are ZK_NTT_PLAIN.  Shape it stays exact
+ * with: zkp/plonk/polynomial.py:316-378. */
+#define ZK_NTT_PLAIN 0
+#define ZK_NTT_BLOCKED_TW 1
+#define ZK_NTT_TRANSPOSED 2
+int zk_ntt_dev_io(zk_ntt_plan *plan, const void *d_in, void *d_out, unsigned batch, int inverse, int in_layout, int out_layout,
+                  unsigned log_block, uint64_t row0, const zk_ntt_plan *big /* nullable unless a side is BLOCKED_TW */, int tw_inverse,
+                  void *stream);
 /* Twiddle between the two dimensions of a four-step transform of the PLAN's size n = 2^log_n whose second
  * dimension has 2^log_cols points:  d_data[b * 2^log_cols + k] *= omega_n^(+-(row0 + b) * k)  for b < rows.
  * Together with zk_ntt_dev_batch this is the local work of the multi-GPU single large NTT

@@ -607,6 +607,17 @@ int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int invers
         return ZK_OK;
     });
 }
+int zk_ntt_dev_io(zk_ntt_plan *plan, const void *d_in, void *d_out, unsigned batch, int inverse, int in_layout, int out_layout, unsigned log_block,
+                  uint64_t row0, const zk_ntt_plan *big, int tw_inverse, void *stream) {
+    return guarded([&] {
+        if (!plan || (batch && (!d_in || !d_out))) return invalid("zk_ntt_dev_io: null pointer");
+        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev_io")) return rc;
+        if (big && big->impl->device() != plan->impl->device()) return invalid("zk_ntt_dev_io: the two plans live on different devices");
+        plan->impl->run_io(d_in, d_out, inverse != 0, batch, in_layout, out_layout, log_block, row0, big ? big->impl.get() : nullptr, tw_inverse != 0,
+                           (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_ntt_twiddle_dev(zk_ntt_plan *plan, void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, int inverse, void *stream) {
     return guarded([&] {
         if (!plan || (rows && !d_data)) return invalid("zk_ntt_twiddle_dev: null pointer");

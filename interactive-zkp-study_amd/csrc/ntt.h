@@ -20,6 +20,23 @@ struct NttPassParams {
     uint32_t lh;         // low-part bits of the two-level inter-pass twiddle tables
     uint32_t apply_scale;  // final pass: multiply outputs by `scale` (D == 1 inverse)
     uint32_t direct_tw;    // inter-pass twiddles come ready-made from a per-(k, rem) table instead of the two-level one
+    uint32_t gb;           // low bits of the carried dimension that run over the BATCH index (transposed input / output); g - gb run over elements
+};
+
+// How element i of transform b of a batch sits in the caller's buffers: the layouts of the four-step (multi-GPU) transform, read by
+// the first pass's loads and written by the last pass's stores, so that no separate pack / transpose / twiddle pass is needed.
+enum NttLayout : int {
+    NTT_PLAIN = 0,       // b * n + i                                                        (transforms back to back)
+    NTT_BLOCKED_TW = 1,  // (((i >> kbits) * batch + b) << kbits) | (i & (2^kbits - 1)), and the value is multiplied by
+                         // w_N^(+-(row0 + b) * i) of the LARGE transform (N = tw plan's size): per-destination blocks + four-step twiddle
+    NTT_TRANSPOSED = 2,  // i * batch + b                                                   (element-major: the matrix transpose)
+};
+struct NttIoArgs {
+    const Fr *twA = nullptr, *twB = nullptr;  // two-level tables of w_N (Montgomery form), direction chosen by the host
+    uint32_t lh = 0;                          // low bits of that table
+    uint32_t kbits = 0;                       // log2 block length of NTT_BLOCKED_TW
+    uint32_t batch = 1;                       // number of transforms in the batch (layout multiplier)
+    uint64_t row0 = 0;                        // first row index of the batch inside the large transform
 };
 
 // Natural-order in/out radix-2 NTT over F_r of size 2^log_n; omega = 5^((r-1)/n).
@@ -29,6 +46,11 @@ class NttPlan {
     // In-place transform of the device buffer (n * 32 bytes, canonical elements).  Enqueues only.
     // `batch` > 1: that many independent transforms stored back to back (no coset shift).
     void run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st, unsigned batch = 1);
+    // Batched transform between two buffers with the layouts above (in_layout read by the first pass, out_layout written by the
+    // last).  `big` supplies w_N for NTT_BLOCKED_TW (the plan of the large transform; tw_inverse picks w_N^-1).  d_out may be
+    // d_in only when both layouts are NTT_PLAIN.
+    void run_io(const void *d_in, void *d_out, bool inverse, unsigned batch, int in_layout, int out_layout, unsigned kbits, uint64_t row0,
+                const NttPlan *big, bool tw_inverse, hipStream_t st);
     // data[b * 2^log_cols + k] *= omega_n^(+-(row0 + b) * k), b < rows: the twiddle between the two dimensions of a
     // four-step transform of n = 2^log_n points whose second dimension has 2^log_cols points.
     void twiddle_2d(void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, bool inverse, hipStream_t st);
@@ -36,6 +58,7 @@ class NttPlan {
     int device() const { return device_; }
 
   private:
+    void launch_passes(const void *d_in, void *d_out, bool inverse, unsigned batch, int in_layout, int out_layout, const NttIoArgs &io, hipStream_t st);
     void build_tables();
     void coset_tables(const uint64_t k[4], bool inverse);
     unsigned L_;

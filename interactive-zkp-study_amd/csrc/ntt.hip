@@ -126,6 +126,18 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
     }
 }
 
+// Where element i of transform b sits in a caller buffer of layout LAYOUT (ntt.h), in elements.
+template <int LAYOUT> __device__ __forceinline__ size_t io_addr(uint32_t L, const NttIoArgs &io, uint32_t b, uint32_t i) {
+    if (LAYOUT == NTT_PLAIN) return ((size_t)b << L) + i;
+    if (LAYOUT == NTT_BLOCKED_TW) return ((((size_t)(i >> io.kbits)) * io.batch + b) << io.kbits) | (i & ((1u << io.kbits) - 1u));
+    return (size_t)i * io.batch + b;
+}
+// w_N^((row0 + b) * i) from the large transform's two-level table (the four-step twiddle; < 2r, Montgomery form)
+__device__ __forceinline__ Fr io_twiddle(const NttIoArgs &io, uint32_t b, uint32_t i) {
+    const uint64_t e = (io.row0 + b) * (uint64_t)i;
+    return fe_mul(io.twA[e & (((uint64_t)1 << io.lh) - 1)], io.twB[e >> io.lh]);
+}
+
 // One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
 // passes (lazy 9-limb form, 36 B); only the first load and the last store use the canonical
 // 32-byte encoding.  LDS: data[9][tile] (limb-major, slots swizzled: swz) | tw[9][2^lp]: the twiddles of stage s,
@@ -133,21 +145,27 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
 // (one table of w^i indexed i = j << (lp - 1 - s) puts the late stages' few distinct twiddles all on one bank).
 //   IN_CANON : `in` holds canonical elements (first pass), else lazy Fr elements (scratch)
 //   FINAL    : last pass: contiguous digit, digit-reversed (natural-order) canonical store
-template <bool FINAL, bool IN_CANON>
+//   IN_L / OUT_L : layout of the caller's buffers (ntt.h: NttLayout), seen by the first pass's loads (IN_CANON) and the last pass's
+//              stores (FINAL); the scratch between passes is always plain.  The tile carries 2^g "bystander" columns next to the
+//              digit: 2^(g - gb) adjacent ELEMENTS and 2^gb adjacent TRANSFORMS of the batch (gb > 0 only with a transposed
+//              buffer, whose memory runs along the batch index), so that both sides of a transposing pass move >= 128-byte runs.
+template <bool FINAL, bool IN_CANON, int IN_L, int OUT_L>
 __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict__ in_v, void *__restrict__ out_v,
                                                           const Fr *__restrict__ tile_tw, const Fr *__restrict__ twA,
-                                                          const Fr *__restrict__ twB, Fr scale, NttPassParams P) {
+                                                          const Fr *__restrict__ twB, Fr scale, NttPassParams P, NttIoArgs io) {
     extern __shared__ uint32_t lds[];
     const uint32_t t = threadIdx.x;
     const uint32_t lp = P.lp, g = P.g, G = 1u << g;
+    constexpr bool HAS_GB = (IN_L == NTT_TRANSPOSED || OUT_L == NTT_TRANSPOSED);
+    const uint32_t gb = HAS_GB ? P.gb : 0u, ga = g - gb, Gb1 = (1u << gb) - 1u, Ga1 = (1u << ga) - 1u;
     const uint32_t tile = 1u << (lp + g);
     const uint32_t ntw = 1u << lp;
     uint32_t *data = lds;
     uint32_t *tw = lds + NL * tile;
-    // blockIdx.y = index of the transform inside a batch of independent, contiguous transforms
-    const size_t boff = (size_t)blockIdx.y << P.L;
-    const uint32_t *in_c = static_cast<const uint32_t *>(in_v) + boff * 8;
-    const Fr *in_l = static_cast<const Fr *>(in_v) + boff;
+    // blockIdx.y = index of the transform (of the group of 2^gb transforms) inside a batch of independent transforms
+    const uint32_t bbase = blockIdx.y << gb;
+    const uint32_t *in_c = static_cast<const uint32_t *>(in_v);
+    const Fr *in_l = static_cast<const Fr *>(in_v);
 
     for (uint32_t i = t + 1; i < ntw; i += NTT_NT) {
         const uint32_t st = 31u - (uint32_t)__clz((int)i), j = i - (1u << st);
@@ -157,22 +175,44 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     const uint32_t tile_id = blockIdx.x;
     uint32_t base_addr = 0, mid = 0, k1_base = 0, mid_in = 0;
     if (!FINAL) {
-        mid = tile_id & ((1u << (P.sp - g)) - 1u);
-        const uint32_t hi = tile_id >> (P.sp - g);
-        base_addr = (hi << (P.sp + lp)) + (mid << g);
+        mid = tile_id & ((1u << (P.sp - ga)) - 1u);
+        const uint32_t hi = tile_id >> (P.sp - ga);
+        base_addr = (hi << (P.sp + lp)) + (mid << ga);
         for (uint32_t e = t; e < tile; e += NTT_NT) {
-            const uint32_t j = e >> g, c = e & (G - 1u);
-            const size_t addr = (size_t)base_addr + ((size_t)j << P.sp) + c;
-            lds_st(data, tile, swz(e), IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
+            const uint32_t j = e >> g, c = e & (G - 1u), cb = c & Gb1, ca = c >> gb;   // the batch bits run fastest
+            const uint32_t i = base_addr + (j << P.sp) + ca, b = bbase + cb;
+            Fr v;
+            if (IN_CANON) {
+                v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
+                if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
+            } else {
+                v = in_l[((size_t)b << P.L) + i];
+            }
+            lds_st(data, tile, swz(e), v);
         }
     } else {
         const uint32_t lmid_tot = (P.nmid > 0 ? P.lmid[0] : 0) + (P.nmid > 1 ? P.lmid[1] : 0);
         mid_in = tile_id & ((1u << lmid_tot) - 1u);
-        k1_base = (tile_id >> lmid_tot) << g;
+        k1_base = (tile_id >> lmid_tot) << ga;
         for (uint32_t e = t; e < tile; e += NTT_NT) {
-            const uint32_t c = e >> lp, j = e & ((1u << lp) - 1u);
-            const size_t addr = ((size_t)(k1_base + c) << (P.L - P.l1)) + ((size_t)mid_in << lp) + j;
-            lds_st(data, tile, swz((j << g) | c), IN_CANON ? ld_canon(in_c + addr * 8) : in_l[addr]);
+            uint32_t c, j;
+            if (IN_CANON && IN_L == NTT_TRANSPOSED) {   // memory runs along the batch index: those bits fastest
+                c = e & (G - 1u);
+                j = e >> g;
+            } else {
+                c = e >> lp;
+                j = e & ((1u << lp) - 1u);
+            }
+            const uint32_t cb = c & Gb1, ca = c >> gb;
+            const uint32_t i = ((k1_base + ca) << (P.L - P.l1)) + (mid_in << lp) + j, b = bbase + cb;
+            Fr v;
+            if (IN_CANON) {
+                v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
+                if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
+            } else {
+                v = in_l[((size_t)b << P.L) + i];
+            }
+            lds_st(data, tile, swz((j << g) | c), v);
         }
     }
     __syncthreads();
@@ -193,22 +233,23 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     }
 
     if (!FINAL) {
-        Fr *out_l = static_cast<Fr *>(out_v) + boff;
+        Fr *out_l = static_cast<Fr *>(out_v);
         const uint32_t sh = P.L - lp - P.sp;
         for (uint32_t e = t; e < tile; e += NTT_NT) {   // in LDS order: the digit comes out bit-reversed, k = brev(position)
-            const uint32_t jpos = e >> g, c = e & (G - 1u);
+            // the scratch runs along the element index: those bits fastest (with gb == 0 this is the LDS order itself)
+            const uint32_t jpos = e >> g, r = e & (G - 1u), ca = r & Ga1, cb = r >> ga, c = (ca << gb) | cb;
             const uint32_t k = lp ? (__brev(jpos) >> (32 - lp)) : 0u;
-            Fr x = lds_ld(data, tile, swz(e));
-            const uint32_t rem = (mid << g) + c;
+            Fr x = lds_ld(data, tile, swz((jpos << g) | c));
+            const uint32_t rem = (mid << ga) + ca;
             const uint32_t ex = (k * rem) << sh;
             // boundaries up to 2^24 entries keep the ready-made twiddle per (k, rem); larger ones build it from the
             // two-level table with one extra multiplication
             const Fr w = P.direct_tw ? twA[((size_t)k << P.sp) + rem] : fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);  // < 2r
             x = fe_mul(x, w);                                                      // 2 * 2 < 169  ->  < 2r
-            out_l[(size_t)base_addr + ((size_t)k << P.sp) + c] = x;
+            out_l[((size_t)(bbase + cb) << P.L) + base_addr + ((size_t)k << P.sp) + ca] = x;
         }
     } else {
-        uint32_t *out_c = static_cast<uint32_t *>(out_v) + boff * 8;
+        uint32_t *out_c = static_cast<uint32_t *>(out_v);
         uint32_t kmid = mid_in, lmid_tot = 0;
         if (P.nmid == 1) {
             lmid_tot = P.lmid[0];
@@ -218,12 +259,13 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             lmid_tot = P.lmid[0] + P.lmid[1];
         }
         for (uint32_t e = t; e < tile; e += NTT_NT) {
-            const uint32_t jpos = e >> g, c = e & (G - 1u);
+            const uint32_t jpos = e >> g, c = e & (G - 1u), cb = c & Gb1, ca = c >> gb;
             const uint32_t k = lp ? (__brev(jpos) >> (32 - lp)) : 0u;
             Fr x = lds_ld(data, tile, swz(e));
             if (P.apply_scale) x = fe_mul(x, scale);
-            const size_t oidx = (size_t)(k1_base + c) + (((size_t)kmid + ((size_t)k << lmid_tot)) << P.l1);
-            st_canon_2r(out_c + oidx * 8, x);
+            const uint32_t oidx = (k1_base + ca) + ((kmid + (k << lmid_tot)) << P.l1), b = bbase + cb;
+            if (OUT_L == NTT_BLOCKED_TW) x = fe_mul(x, io_twiddle(io, b, oidx));   // 2 * 2 < 169  ->  < 2r
+            st_canon_2r(out_c + io_addr<OUT_L>(P.L, io, b, oidx) * 8, x);
         }
     }
 }
@@ -307,6 +349,8 @@ static void upload_powers(DevBuf &buf, HFr base, size_t count, const HFr *scale 
     ZK_HIP(hipMemcpy(buf.p, h.data(), count * sizeof(Fr), hipMemcpyHostToDevice));
 }
 
+static std::vector<const void *> pass_kernel_functions();
+
 NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     if (L_ <= 10) {
         digits_.push_back(L_);
@@ -332,9 +376,7 @@ NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     ZK_HIP(hipGetDevice(&device_));
     bool &attr_done = attr_done_dev[device_ & 63];
     if (!attr_done) {
-        const void *fns[4] = {reinterpret_cast<const void *>(&ntt_pass_kernel<false, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<false, false>),
-                              reinterpret_cast<const void *>(&ntt_pass_kernel<true, true>), reinterpret_cast<const void *>(&ntt_pass_kernel<true, false>)};
-        for (const void *f : fns) ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        for (const void *f : pass_kernel_functions()) ZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;
     }
 }
@@ -389,69 +431,131 @@ void NttPlan::coset_tables(const uint64_t k[4], bool inverse) {
 void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st, unsigned batch) {
     const size_t n = (size_t)1 << L_;
     if (batch == 0) return;
-    if (batch > 65535) throw std::runtime_error("zk_ntt: batch must be <= 65535");
     if (coset_shift && batch != 1) throw std::runtime_error("zk_ntt: coset shifts are not available for batched transforms");
-    if (digits_.size() > 1 && tmp_.bytes < (size_t)batch * n * sizeof(Fr)) {
-        ZK_HIP(hipStreamSynchronize(st));  // the old scratch may still be in use
-        tmp_.alloc((size_t)batch * n * sizeof(Fr));
-    }
     uint32_t *data = static_cast<uint32_t *>(d_data);
-    const int dir = inverse ? 1 : 0;
-    const unsigned D = (unsigned)digits_.size();
     const unsigned blocks_sc = (unsigned)((n + 255) / 256);
     if (coset_shift && !inverse) {
         coset_tables(coset_shift, false);
         hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_[0].as<Fr>(), cosB_[0].as<Fr>(), lh_, n);
     }
-    if (L_ > 0 || inverse) {
-        uint32_t sp = L_;
-        for (unsigned p = 0; p < D; p++) {
-            const uint32_t lp = digits_[p];
-            sp -= lp;
-            NttPassParams P;
-            memset(&P, 0, sizeof(P));
-            P.L = L_; P.lp = lp; P.sp = sp; P.lh = lh_;
-            P.tw_shift = lmax_ - lp;
-            const bool final_pass = (p == D - 1);
-            // tiles of up to 2^10 elements (every thread owns 4; 41 KB of LDS: three workgroups per CU), but never fewer than ~512 tiles per pass
-            P.g = (D == 1) ? 0 : (uint32_t)std::max<int>(NTT_G, std::min<int>(10 - (int)lp, (int)L_ - (int)lp - 9));
-            const void *src = (p == 0) ? static_cast<const void *>(data) : tmp_.p;
-            void *dst = final_pass ? static_cast<void *>(data) : tmp_.p;
-            const uint32_t tile = 1u << (lp + P.g);
-            const size_t lds = ((size_t)NL * tile + (size_t)NL * (1u << lp)) * sizeof(uint32_t);
-            const unsigned blocks = (unsigned)(n >> (lp + P.g));
-            if (!final_pass) {
-                const Fr *B = (inverse && p == 0) ? twB_scaled_inv_.as<Fr>() : twB_[dir].as<Fr>();
-                const Fr *A = twA_[dir].as<Fr>();
-                if (p < 3 && tw_direct_[dir][p].p) {
-                    P.direct_tw = 1;
-                    A = tw_direct_[dir][p].as<Fr>();
-                }
-                if (p == 0)
-                    hipLaunchKernelGGL((ntt_pass_kernel<false, true>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B,
-                                       scale_inv_, P);
-                else
-                    hipLaunchKernelGGL((ntt_pass_kernel<false, false>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B,
-                                       scale_inv_, P);
-            } else {
-                P.l1 = (D == 1) ? 0 : digits_[0];
-                P.nmid = D > 2 ? D - 2 : 0;
-                for (unsigned q = 0; q < P.nmid; q++) P.lmid[q] = digits_[1 + q];
-                P.apply_scale = (inverse && D == 1) ? 1 : 0;
-                if (D == 1)
-                    hipLaunchKernelGGL((ntt_pass_kernel<true, true>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
-                                       twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
-                else
-                    hipLaunchKernelGGL((ntt_pass_kernel<true, false>), dim3(blocks, batch), dim3(NTT_NT), lds, st, src, dst, tile_tw_[dir].as<Fr>(),
-                                       twA_[dir].as<Fr>(), twB_[dir].as<Fr>(), scale_inv_, P);
-            }
-        }
-    }
+    launch_passes(d_data, d_data, inverse, batch, NTT_PLAIN, NTT_PLAIN, NttIoArgs(), st);
     if (coset_shift && inverse) {
         coset_tables(coset_shift, true);
         hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_[1].as<Fr>(), cosB_[1].as<Fr>(), lh_, n);
     }
     ZK_HIP(hipGetLastError());
+}
+
+void NttPlan::run_io(const void *d_in, void *d_out, bool inverse, unsigned batch, int in_layout, int out_layout, unsigned kbits, uint64_t row0,
+                     const NttPlan *big, bool tw_inverse, hipStream_t st) {
+    if (batch == 0) return;
+    for (int lay : {in_layout, out_layout})
+        if (lay != NTT_PLAIN && lay != NTT_BLOCKED_TW && lay != NTT_TRANSPOSED) throw std::runtime_error("zk_ntt: unknown buffer layout");
+    if (d_in == d_out && (in_layout != NTT_PLAIN || out_layout != NTT_PLAIN))
+        throw std::runtime_error("zk_ntt: a transform that changes the layout cannot run in place");
+    NttIoArgs io;
+    io.batch = batch;
+    io.kbits = kbits;
+    io.row0 = row0;
+    if (in_layout == NTT_BLOCKED_TW || out_layout == NTT_BLOCKED_TW) {
+        if (in_layout == out_layout) throw std::runtime_error("zk_ntt: the four-step twiddle belongs to one side of a transform only");
+        if (!big) throw std::runtime_error("zk_ntt: the blocked layout needs the plan of the large transform for its twiddles");
+        if (kbits > L_) throw std::runtime_error("zk_ntt: block length exceeds the transform");
+        if (((row0 + batch) << L_) > ((uint64_t)1 << big->L_)) throw std::runtime_error("zk_ntt: rows exceed the large transform");
+        const int d = tw_inverse ? 1 : 0;
+        io.twA = big->twA_[d].as<Fr>();
+        io.twB = big->twB_[d].as<Fr>();
+        io.lh = big->lh_;
+    }
+    launch_passes(d_in, d_out, inverse, batch, in_layout, out_layout, io, st);
+    ZK_HIP(hipGetLastError());
+}
+
+// The pass-kernel instantiations in use: <FINAL, IN_CANON, IN_L, OUT_L>; buffers other than the first pass's input and the last
+// pass's output are the plan's scratch (plain).
+#define ZK_NTT_PASS_CASES(X)                                                                                                   \
+    X(false, true, NTT_PLAIN, NTT_PLAIN) X(false, true, NTT_BLOCKED_TW, NTT_PLAIN) X(false, true, NTT_TRANSPOSED, NTT_PLAIN)  \
+    X(false, false, NTT_PLAIN, NTT_PLAIN)                                                                                      \
+    X(true, false, NTT_PLAIN, NTT_PLAIN) X(true, false, NTT_PLAIN, NTT_BLOCKED_TW) X(true, false, NTT_PLAIN, NTT_TRANSPOSED)   \
+    X(true, true, NTT_PLAIN, NTT_PLAIN) X(true, true, NTT_PLAIN, NTT_BLOCKED_TW) X(true, true, NTT_PLAIN, NTT_TRANSPOSED)      \
+    X(true, true, NTT_BLOCKED_TW, NTT_PLAIN) X(true, true, NTT_TRANSPOSED, NTT_PLAIN) X(true, true, NTT_TRANSPOSED, NTT_TRANSPOSED) \
+    X(true, true, NTT_BLOCKED_TW, NTT_TRANSPOSED) X(true, true, NTT_TRANSPOSED, NTT_BLOCKED_TW)
+static std::vector<const void *> pass_kernel_functions() {
+    std::vector<const void *> v;
+#define X(F, C, I, O) v.push_back(reinterpret_cast<const void *>(&ntt_pass_kernel<F, C, I, O>));
+    ZK_NTT_PASS_CASES(X)
+#undef X
+    return v;
+}
+static void launch_pass(bool fin, bool canon, int in_l, int out_l, dim3 grid, size_t lds, hipStream_t st, const void *src, void *dst, const Fr *tile_tw,
+                        const Fr *A, const Fr *B, Fr scale, const NttPassParams &P, const NttIoArgs &io) {
+#define X(F, C, I, O)                                                                                                          \
+    if (fin == F && canon == C && in_l == I && out_l == O) {                                                                   \
+        hipLaunchKernelGGL((ntt_pass_kernel<F, C, I, O>), grid, dim3(NTT_NT), lds, st, src, dst, tile_tw, A, B, scale, P, io); \
+        return;                                                                                                                \
+    }
+    ZK_NTT_PASS_CASES(X)
+#undef X
+    throw std::runtime_error("zk_ntt: this combination of buffer layouts is not available");
+}
+
+void NttPlan::launch_passes(const void *d_in, void *d_out, bool inverse, unsigned batch, int in_layout, int out_layout, const NttIoArgs &io,
+                            hipStream_t st) {
+    const size_t n = (size_t)1 << L_;
+    if (batch > 65535) throw std::runtime_error("zk_ntt: batch must be <= 65535");
+    if (digits_.size() > 1 && tmp_.bytes < (size_t)batch * n * sizeof(Fr)) {
+        ZK_HIP(hipStreamSynchronize(st));  // the old scratch may still be in use
+        tmp_.alloc((size_t)batch * n * sizeof(Fr));
+    }
+    const int dir = inverse ? 1 : 0;
+    const unsigned D = (unsigned)digits_.size();
+    const bool plain = in_layout == NTT_PLAIN && out_layout == NTT_PLAIN;
+    // transposed buffers run along the batch index: up to four transforms side by side in a tile
+    uint32_t gb_max = 0;
+    while (gb_max < 2 && batch % (2u << gb_max) == 0) gb_max++;
+    if (!(L_ > 0 || inverse || !plain)) return;
+    uint32_t sp = L_;
+    for (unsigned p = 0; p < D; p++) {
+        const uint32_t lp = digits_[p];
+        sp -= lp;
+        NttPassParams P;
+        memset(&P, 0, sizeof(P));
+        P.L = L_; P.lp = lp; P.sp = sp; P.lh = lh_;
+        P.tw_shift = lmax_ - lp;
+        const bool first_pass = (p == 0), final_pass = (p == D - 1);
+        const int il = first_pass ? in_layout : NTT_PLAIN, ol = final_pass ? out_layout : NTT_PLAIN;
+        const bool transposing = il == NTT_TRANSPOSED || ol == NTT_TRANSPOSED;
+        // tiles of up to 2^10 elements (every thread owns 4; 41 KB of LDS: three workgroups per CU), but never fewer than ~512 tiles per pass
+        // (a batch in one of the four-step layouts has its tiles from all the transforms together)
+        const int room = plain ? (int)L_ - (int)lp - 9 : 10 - (int)lp;
+        P.g = (D == 1) ? 0 : (uint32_t)std::max<int>(NTT_G, std::min<int>(10 - (int)lp, room));
+        if (transposing) {
+            P.gb = std::min<uint32_t>(gb_max, 10 - lp);
+            if (D == 1) P.g = P.gb;                                   // every carried column is a transform of its own
+            else P.g = std::max(P.g, P.gb);
+            if (!final_pass) P.g = std::min<uint32_t>(P.g, sp + P.gb);  // the element columns come out of the sp low bits
+        }
+        const void *src = first_pass ? d_in : static_cast<const void *>(tmp_.p);
+        void *dst = final_pass ? d_out : tmp_.p;
+        const uint32_t tile = 1u << (lp + P.g);
+        const size_t lds = ((size_t)NL * tile + (size_t)NL * (1u << lp)) * sizeof(uint32_t);
+        const unsigned blocks = (unsigned)(n >> (lp + P.g - P.gb));
+        const dim3 grid(blocks, batch >> P.gb);
+        const Fr *A = twA_[dir].as<Fr>(), *B = twB_[dir].as<Fr>();
+        if (!final_pass) {
+            if (inverse && p == 0) B = twB_scaled_inv_.as<Fr>();
+            if (p < 3 && tw_direct_[dir][p].p) {
+                P.direct_tw = 1;
+                A = tw_direct_[dir][p].as<Fr>();
+            }
+        } else {
+            P.l1 = (D == 1) ? 0 : digits_[0];
+            P.nmid = D > 2 ? D - 2 : 0;
+            for (unsigned q = 0; q < P.nmid; q++) P.lmid[q] = digits_[1 + q];
+            P.apply_scale = (inverse && D == 1) ? 1 : 0;
+        }
+        launch_pass(final_pass, first_pass, il, ol, grid, lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B, scale_inv_, P, io);
+    }
 }
 
 void NttPlan::twiddle_2d(void *d_data, unsigned log_cols, uint64_t rows, uint64_t row0, bool inverse, hipStream_t st) {

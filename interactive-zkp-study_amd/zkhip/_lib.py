@@ -21,6 +21,7 @@ ZK_ERR_NO_DEVICE = -3
 ZK_ERR_NOMEM = -4
 GROUP_G1 = 1
 GROUP_G2 = 2
+NTT_PLAIN, NTT_BLOCKED_TW, NTT_TRANSPOSED = 0, 1, 2   # buffer layouts of zk_ntt_dev_io
 
 
 class ZkhipError(RuntimeError):
@@ -63,6 +64,7 @@ _PROTOS = {
     "zk_ntt_plan_destroy": (ctypes.c_int, [_VP]),
     "zk_ntt_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_int, _VP, _VP]),
     "zk_ntt_dev_batch": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_int, _VP]),
+    "zk_ntt_dev_io": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64, _VP, ctypes.c_int, _VP]),
     "zk_ntt_twiddle_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _VP]),
     "zk_fr_quotient_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "zk_fr_spmv_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),

@@ -132,6 +132,12 @@ class NttPlan:
         """`batch` independent transforms stored back to back in d_data (zk_ntt_dev_batch)."""
         _lib.check(_lib.load().zk_ntt_dev_batch(self._h, d_data, int(batch), 1 if inverse else 0, stream))
 
+    def run_io(self, d_in, d_out, batch, inverse=False, in_layout=0, out_layout=0, log_block=0, row0=0, big=None, tw_inverse=False, stream=0):
+        """`batch` transforms from d_in to d_out in the four-step layouts (_lib.NTT_PLAIN / NTT_BLOCKED_TW / NTT_TRANSPOSED;
+        zk_ntt_dev_io): pack, transpose and the twiddle of the large transform `big` happen in the first loads / last stores."""
+        _lib.check(_lib.load().zk_ntt_dev_io(self._h, d_in, d_out, int(batch), 1 if inverse else 0, int(in_layout), int(out_layout), int(log_block),
+                                              int(row0), None if big is None else big._h, 1 if tw_inverse else 0, stream))
+
     def twiddle(self, d_data, log_cols, rows, row0, inverse=False, stream=0):
         """d_data[b * 2^log_cols + k] *= omega_n^(+-(row0 + b) * k) for b < rows, n = this plan's size (zk_ntt_twiddle_dev)."""
         _lib.check(_lib.load().zk_ntt_twiddle_dev(self._h, d_data, int(log_cols), int(rows), int(row0), 1 if inverse else 0, stream))

@@ -230,13 +230,18 @@ class ExchangeWorker:
 # forward transform takes BC(n2) and leaves BC(n1) (the same layout when n1 == n2, i.e. for even log n); the inverse
 # takes BC(n1) back to BC(n2).  Pointwise work between a forward and an inverse transform (the quotient of a prover)
 # is layout-agnostic, and an MSM over BC-distributed scalars only needs its points distributed the same way.
-#   1. local: the n2/R owned columns are contiguous rows -> n2/R transforms of length n1 in place (zk_ntt_dev_batch)
-#   2. local: twiddle w_n^(j2 k1)                                  (zk_ntt_twiddle_dev)
-#   3. pack per destination, then ONE all-to-all: rank r sends rank s the k1-block of s of its columns (n/R^2
-#      elements per pair; every pair of GPUs has its own xGMI link, so all links carry traffic at once)
-#   4. local: transpose to [k1 local][j2], n1/R transforms of length n2 in place -- already the BC(n1) storage
+#   1. local: the n2/R owned columns are contiguous rows -> n2/R transforms of length n1; the last pass multiplies by the twiddle
+#      w_n^(j2 k1) and stores every result straight into its destination's block of the send buffer
+#   2. ONE all-to-all: rank r sends rank s the k1-block of s of its columns (n/R^2 elements per pair; every pair of GPUs has its
+#      own xGMI link, so all links carry traffic at once)
+#   3. local: n1/R transforms of length n2 whose first pass reads the received [j2][k1 local] matrix transposed -- already the
+#      BC(n1) storage.
+# On the GPU steps 1 and 3 are zk_ntt_dev_io calls (the pack, the twiddle and the transpose happen in the pass kernels' first
+# loads / last stores); `_HipLocal.fused` marks that.  The CPU tests inject a local object without it and take the explicit
+# ntt_rows / twiddle / permute route below, which defines what the fused kernels must reproduce.
 class _HipLocal:
     """The local kernels of DistNtt on this process's GPU."""
+    fused = True
 
     def __init__(self, log_n, l1, l2):
         from .device import NttPlan
@@ -253,6 +258,13 @@ class _HipLocal:
         """t: (rows, cols, 4): t[b, k] *= w_n^(+-(row0 + b) k)."""
         import torch
         self.pn.twiddle(t.data_ptr(), t.shape[1].bit_length() - 1, t.shape[0], row0, inverse, torch.cuda.current_stream().cuda_stream)
+
+    def io(self, which, src, dst, batch, inverse, in_layout, out_layout, log_block=0, row0=0):
+        """zk_ntt_dev_io on the current stream: `batch` transforms of dimension `which` from src to dst in the given layouts."""
+        import torch
+        plan = self.p1 if which == 1 else self.p2
+        plan.run_io(src.data_ptr(), dst.data_ptr(), batch, inverse, in_layout, out_layout, log_block, row0, self.pn, inverse,
+                    torch.cuda.current_stream().cuda_stream)
 
 
 class DistNtt:
@@ -308,10 +320,22 @@ class DistNtt:
         dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
         return recv
 
-    def forward(self, x):
+    def forward(self, x, natural_in=False, natural_out=False):
         """x: (c, n1, 4) int64 tensor, this rank's BC(n2) block (transformed in place as scratch) -> (k, n2, 4), its
-        BC(n1) block of the transform."""
+        BC(n1) block of the transform.  On one rank the layouts may also be the natural order (x[j] at j in, X[k] at k
+        out; any shape with n elements): the transposes that takes are the same first loads / last stores."""
         R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
+        if (natural_in or natural_out) and (R != 1 or not getattr(self.local, "fused", False)):
+            raise ValueError("DistNtt: natural-order input / output is offered on one rank with the GPU kernels only")
+        if getattr(self.local, "fused", False):
+            import torch
+            from ._lib import NTT_BLOCKED_TW, NTT_PLAIN, NTT_TRANSPOSED
+            send = torch.empty((R, c, k, 4), dtype=x.dtype, device=x.device)
+            self.local.io(1, x, send, c, False, NTT_TRANSPOSED if natural_in else NTT_PLAIN, NTT_BLOCKED_TW, k.bit_length() - 1, self.rank * c)
+            recv = self._exchange(send)                                   # [r][c][k1 local]  ==  [j2][k1 local]
+            rows = x.view(-1)[:k * n2 * 4].view(k, n2, 4) if x.numel() == k * n2 * 4 else torch.empty((k, n2, 4), dtype=x.dtype, device=x.device)
+            self.local.io(2, recv, rows, k, False, NTT_TRANSPOSED, NTT_TRANSPOSED if natural_out else NTT_PLAIN)
+            return rows
         self.local.ntt_rows(x, 1, False)                              # [c][j1] -> [c][k1]
         self.local.twiddle(x, self.rank * c, False)                   # * w_n^(j2 k1), j2 = rank*c + c_local
         send = x.view(c, R, k, 4).permute(1, 0, 2, 3).contiguous()    # [s][c][k1 local of s]
@@ -320,10 +344,21 @@ class DistNtt:
         self.local.ntt_rows(rows, 2, False)                           # [k1 local][k2]
         return rows
 
-    def inverse(self, y):
+    def inverse(self, y, natural_in=False, natural_out=False):
         """y: (k, n2, 4), a BC(n1) block (used as scratch) -> (c, n1, 4), the BC(n2) block of the inverse transform
-        (1/n included)."""
+        (1/n included).  natural_in / natural_out: as in forward."""
         R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
+        if (natural_in or natural_out) and (R != 1 or not getattr(self.local, "fused", False)):
+            raise ValueError("DistNtt: natural-order input / output is offered on one rank with the GPU kernels only")
+        if getattr(self.local, "fused", False):
+            import torch
+            from ._lib import NTT_BLOCKED_TW, NTT_PLAIN, NTT_TRANSPOSED
+            send = torch.empty((R, c, k, 4), dtype=y.dtype, device=y.device)     # [s][c local of s][k1 local]
+            self.local.io(2, y, send, k, True, NTT_TRANSPOSED if natural_in else NTT_PLAIN, NTT_TRANSPOSED)   # (1/n2 applied)
+            recv = self._exchange(send)                                   # [r][c][k1 local of r]: the blocked layout of [c][k1]
+            cols = y.view(-1)[:c * n1 * 4].view(c, n1, 4)
+            self.local.io(1, recv, cols, c, True, NTT_BLOCKED_TW, NTT_TRANSPOSED if natural_out else NTT_PLAIN, k.bit_length() - 1, self.rank * c)
+            return cols                                                   # * w_n^(-j2 k1), then [c][j1]   (1/n1 applied)
         self.local.ntt_rows(y, 2, True)                               # [k1 local][k2] -> [k1 local][j2]   (1/n2 applied)
         send = y.view(k, R, c, 4).permute(1, 2, 0, 3).contiguous()    # [s][c local of s][k1 local]
         recv = self._exchange(send)                                   # [r][c][k1 local of r]

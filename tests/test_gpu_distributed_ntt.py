@@ -60,6 +60,61 @@ def test_twiddle_2d_kernel():
         assert got == want
 
 
+@pytest.mark.parametrize("log_n,batch,log_block,big_log", [(1, 2, 0, 2), (4, 8, 2, 9), (6, 16, 3, 12), (8, 12, 8, 13), (10, 64, 7, 16), (11, 32, 9, 16), (12, 256, 10, 20),
+                                                           (13, 8, 5, 17), (16, 4, 14, 18)])
+def test_ntt_io_layouts_against_the_separate_passes(log_n, batch, log_block, big_log):
+    """zk_ntt_dev_io: the four-step layouts read by the first loads / written by the last stores must give exactly what the
+    separate passes give -- batched transform (zk_ntt_dev_batch), 2-D twiddle (zk_ntt_twiddle_dev) and a numpy permutation."""
+    import torch
+    from zkhip._lib import NTT_BLOCKED_TW, NTT_PLAIN, NTT_TRANSPOSED
+    rng = np.random.default_rng(900 + log_n)
+    n, kb = 1 << log_n, 1 << log_block
+    row0 = ((1 << big_log) >> log_n) - batch                               # the last rows of the large transform
+    assert row0 >= 0
+    X = rand_fr_limbs(rng, n * batch).reshape(batch, n, 4)
+    st = torch.cuda.current_stream().cuda_stream
+    plan, big = NttPlan(log_n), NttPlan(big_log)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    blocked = lambda a: np.ascontiguousarray(a.reshape(batch, n // kb, kb, 4).transpose(1, 0, 2, 3)).reshape(batch, n, 4)
+    unblocked = lambda a: np.ascontiguousarray(a.reshape(n // kb, batch, kb, 4).transpose(1, 0, 2, 3)).reshape(batch, n, 4)
+    transposed = lambda a: np.ascontiguousarray(a.transpose(1, 0, 2))       # (batch, n, 4) -> (n, batch, 4)
+    for inverse in (False, True):
+        rows = dev(X)
+        plan.run_batch(rows.data_ptr(), batch, inverse, st)
+        want_rows = host(rows).copy()                                       # the plain batched transform
+        tw = dev(want_rows)
+        big.twiddle(tw.data_ptr(), log_n, batch, row0, inverse, st)
+        want_tw = host(tw).copy()                                           # ... times w_N^(+-(row0 + b) i)
+        out = torch.zeros_like(rows)
+        # plain in, blocked + twiddle out (forward step 1 of the four-step transform)
+        plan.run_io(dev(X).data_ptr(), out.data_ptr(), batch, inverse, NTT_PLAIN, NTT_BLOCKED_TW, log_block, row0, big, inverse, st)
+        assert np.array_equal(host(out).reshape(batch, n, 4), blocked(want_tw)), ("out blocked", inverse)
+        # transposed in (forward step 3), plain / transposed out
+        plan.run_io(dev(transposed(X)).data_ptr(), out.data_ptr(), batch, inverse, NTT_TRANSPOSED, NTT_PLAIN, 0, 0, None, False, st)
+        assert np.array_equal(host(out).reshape(batch, n, 4), want_rows), ("in transposed", inverse)
+        plan.run_io(dev(transposed(X)).data_ptr(), out.data_ptr(), batch, inverse, NTT_TRANSPOSED, NTT_TRANSPOSED, 0, 0, None, False, st)
+        assert np.array_equal(host(out).reshape(n, batch, 4), transposed(want_rows)), ("in / out transposed", inverse)
+        plan.run_io(dev(X).data_ptr(), out.data_ptr(), batch, inverse, NTT_PLAIN, NTT_TRANSPOSED, 0, 0, None, False, st)
+        assert np.array_equal(host(out).reshape(n, batch, 4), transposed(want_rows)), ("out transposed", inverse)
+        # blocked + twiddle in (inverse step 3): the twiddle comes BEFORE the transform
+        pre = dev(X)
+        big.twiddle(pre.data_ptr(), log_n, batch, row0, inverse, st)
+        plan.run_batch(pre.data_ptr(), batch, inverse, st)
+        plan.run_io(dev(blocked(X)).data_ptr(), out.data_ptr(), batch, inverse, NTT_BLOCKED_TW, NTT_PLAIN, log_block, row0, big, inverse, st)
+        assert np.array_equal(host(out).reshape(batch, n, 4), host(pre)), ("in blocked", inverse)
+        plan.run_io(dev(blocked(X)).data_ptr(), out.data_ptr(), batch, inverse, NTT_BLOCKED_TW, NTT_TRANSPOSED, log_block, row0, big, inverse, st)
+        assert np.array_equal(host(out).reshape(n, batch, 4), transposed(host(pre))), ("in blocked, out transposed", inverse)
+        plan.run_io(dev(transposed(X)).data_ptr(), out.data_ptr(), batch, inverse, NTT_TRANSPOSED, NTT_BLOCKED_TW, log_block, row0, big, inverse, st)
+        assert np.array_equal(host(out).reshape(batch, n, 4), blocked(want_tw)), ("in transposed, out blocked", inverse)
+    d = dev(X)
+    with pytest.raises(Exception):
+        plan.run_io(d.data_ptr(), d.data_ptr(), batch, False, NTT_PLAIN, NTT_TRANSPOSED, 0, 0, None, False, st)    # layout change in place
+    with pytest.raises(Exception):
+        plan.run_io(d.data_ptr(), out.data_ptr(), batch, False, NTT_PLAIN, NTT_BLOCKED_TW, log_block, 0, None, False, st)   # no large plan
+    assert unblocked(blocked(X)).tobytes() == X.tobytes()
+
+
 @pytest.mark.parametrize("log_n,l1", [(2, None), (9, 3), (12, None), (13, 6), (16, None), (20, None), (21, 11)])
 def test_four_step_single_rank_matches_direct(log_n, l1):
     """world 1: the whole vector in residue-major storage; forward() must equal the direct plan bit for bit."""
@@ -74,6 +129,20 @@ def test_four_step_single_rank_matches_direct(log_n, l1):
     assert np.array_equal(y.cpu().numpy().view(np.uint64), d.scatter_out(_direct(full, log_n)))
     back = d.inverse(y)
     assert np.array_equal(back.cpu().numpy().view(np.uint64), d.scatter_in(full))
+    # natural order in and out (one rank): the four-step route as a whole against the direct plan, and the explicit
+    # transform / twiddle / permute route (what the CPU tests run with the oracle as local transform) against both
+    nat = torch.from_numpy(full.view(np.int64).copy()).cuda()
+    fwd = d.forward(nat, natural_in=True, natural_out=True)
+    assert np.array_equal(fwd.cpu().numpy().view(np.uint64).reshape(-1, 4), _direct(full, log_n))
+    inv = d.inverse(fwd, natural_in=True, natural_out=True)
+    assert np.array_equal(inv.cpu().numpy().view(np.uint64).reshape(-1, 4), full)
+
+    class Unfused(type(d.local)):
+        fused = False
+    du = DistNtt(log_n, l1=l1, local=Unfused(log_n, d.l1, d.l2))
+    yu = du.forward(torch.from_numpy(d.scatter_in(full).view(np.int64)).cuda())
+    assert np.array_equal(yu.cpu().numpy().view(np.uint64), d.scatter_out(_direct(full, log_n)))
+    assert np.array_equal(du.inverse(yu).cpu().numpy().view(np.uint64), d.scatter_in(full))
 
 
 def _worker(rank, world, port, log_n, l1, ret):

@@ -99,10 +99,11 @@ def test_scale_prover_2pow20_constraints_closed_form():
     assert torch.equal(prover.abc[0], _dev(a)) and torch.equal(prover.abc[1], _dev(b))   # A.w and B.w of the device mat-vec
     assert (pa, pb, pc) == prover.prove_from_witness(d_w, r, s)[:3]
     # From 2^21 constraints on the merged proof_C query exceeds one 2^22-point chunk and is submitted while the A query is still
-    # in flight on the same plan: the same situation here with 2^20-point chunks (3 m + 4 bases = three chunks and a bit).
+    # in flight on the same plan: the same situation here with 2^21-point chunks (the A query, m + 3 bases, still fits one; the
+    # merged query's 3 m + 4 bases are a chunk and a half).
     del prover
     torch.cuda.empty_cache()
-    chunked = ScaleProver(crs, chunk_log=20)
+    chunked = ScaleProver(crs, chunk_log=21)
     chunked.load_r1cs(circ.r1cs_csr())
     assert (pa, pb, pc) == chunked.prove_from_witness(d_w, r, s)[:3]
 
