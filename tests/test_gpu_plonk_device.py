@@ -155,15 +155,18 @@ def test_device_grand_product_with_a_zero_denominator_equals_the_reference_loop(
     beta = 0x1234567
     gamma = (-(int(a[zero_row]) + beta * int(s1[zero_row]))) % R          # a_i + beta * sigma_1(i) + gamma = 0
     want = pl.compute_accumulator([int(v) for v in a], [int(v) for v in b], [int(v) for v in c], list(pp.sigma), n, [int(d) for d in pp.domain], beta, gamma)
-    if zero_row < n - 1:
-        assert all(v == 0 for v in want[zero_row + 1:]) and all(v != 0 for v in want[:zero_row + 1])
-    else:
-        assert all(v != 0 for v in want)                                  # the last row's denominator never enters z
+    # (a wired position shares its label with its partner, whose NUMERATOR factor vanishes as well: z may already be 0 one row earlier)
+    assert want[0] == 1 and all(v == 0 for v in want[zero_row + 1:])
     assert [int(v) for v in compute_accumulator(a, b, c, pp.sigma, n, pp.domain, FR(beta), FR(gamma))] == want
     import torch
     cols = [torch.from_numpy(_limbs(col).view(np.int64)).cuda() for col in (a, b, c)]
+    exact_calls = []
+    exact = dev._accumulator_exact
+    dev._accumulator_exact = lambda num, den: (exact_calls.append(1), exact(num, den))[1]
     got = dev._accumulator(cols, beta, gamma)
+    assert exact_calls == [1]                                             # the zero total was seen and took the row-exact path
     assert _lib.limbs_to_ints(got.cpu().numpy().view(np.uint64)) == want
     # and with ordinary challenges the scan path gives the same z as the loop
     want2 = pl.compute_accumulator([int(v) for v in a], [int(v) for v in b], [int(v) for v in c], list(pp.sigma), n, [int(d) for d in pp.domain], 77, 99)
     assert _lib.limbs_to_ints(dev._accumulator(cols, 77, 99).cpu().numpy().view(np.uint64)) == want2
+    assert exact_calls == [1]                                             # ... without the host path
