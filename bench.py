@@ -36,7 +36,32 @@ sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
 
 HBM_PEAK_GBS = 8000.0
 G1_BYTES_PER_POINT = 96  # 32 B scalar + 64 B affine point, each read once
-MADS_PER_MADD = 1467     # v_mad_u64_u32 in one XYZZ += affine addition as compiled (code object of msm_accumulate_kernel<Fp>)
+
+
+def arithmetic_source_hash():
+    """SHA-256 over the sources that determine what one bucket addition compiles to: csrc/field.h, csrc/curve.h and the accumulate
+    kernel's text in csrc/msm_impl.h (sum_list .. msm_accumulate_kernel).  Figures that were NOT measured by this run but read off
+    a compiled code object or a committed counter pass (profiles/static_counts.json, profiles/*_pmc_sq_summary.csv) carry the hash of
+    the sources they were taken from and are dropped from the line when it no longer matches."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "interactive-zkp-study_amd", "csrc")
+    for name in ("field.h", "curve.h"):
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    text = open(os.path.join(csrc, "msm_impl.h")).read()
+    a, b = text.index("template <class F>\n__device__ __forceinline__ Xyzz<F> sum_list("), text.index("// Heavy buckets, stage 0")
+    h.update(text[a:b].encode())
+    return h.hexdigest()
+
+
+def static_counts():
+    """profiles/static_counts.json when it belongs to the current arithmetic sources, else None."""
+    path = os.path.join(ROOT, "profiles", "static_counts.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return rec if rec.get("arithmetic_source_sha256") == arithmetic_source_hash() else None
 
 
 from zkhip.synthetic import (R_MOD, arithmetic_dot_device, arithmetic_points, limbs_dot_mod_r, random_scalars,  # noqa: E402
@@ -57,10 +82,18 @@ def committed_issue_rate(kernel):
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq_summary.csv")))
     if not found:
         return None
+    meta = found[-1][:-4] + ".meta.json"
+    try:
+        tagged = json.load(open(meta)).get("arithmetic_source_sha256")
+    except (OSError, ValueError):
+        tagged = None
+    if tagged is not None and tagged != arithmetic_source_hash():
+        return None                                 # the counter pass was taken from other arithmetic sources: do not quote it
     for r in csv.DictReader(open(found[-1])):
         if r["kernel"] == kernel:
             v = float(r["valu_insts_per_simd_cycle"])
             return {"source": os.path.relpath(found[-1], ROOT), "insts_per_simd_cycle": v, "peak": 0.25, "frac": v / 0.25,
+                    "arithmetic_source_sha256": tagged,
                     "note": "a wave64 vector instruction occupies a SIMD for 4 cycles; counters of a separate rocprofv3 --pmc run, not of this one"}
     return None
 
@@ -639,10 +672,15 @@ def main():
         alu = {"unit": "G1 mixed additions/s", "per_launch": madds, "achieved": madds / acc_s if acc_s > 0 else 0.0, "peak": madd_peak,
                "frac": (madds / acc_s / madd_peak) if acc_s > 0 else 0.0, "modmul_peak_per_s": modmul_peak,
                "modmul_per_madd": 10, "note": "peak = zk_measure_rate(1): dependent XYZZ+=affine chains, one wave per workgroup, chip oversubscribed",
-               # the ceiling that does not depend on this library's arithmetic: the chip's v_mad_u64_u32 issue rate (zk_measure_rate(2): bare
-               # independent multiply-adds, as tools/ubench.hip) against the multiply-adds one mixed addition compiles to
-               "mad_floor": {"v_mad_u64_u32_lane_ops_per_s": mad_rate, "mads_per_madd": MADS_PER_MADD, "floor_ms": madds * MADS_PER_MADD / mad_rate * 1e3,
-                             "frac": (madds * MADS_PER_MADD / mad_rate) / acc_s if acc_s > 0 else 0.0}}
+               "v_mad_u64_u32_lane_ops_per_s": mad_rate}
+        # the ceiling that does not depend on this library's arithmetic: the chip's v_mad_u64_u32 issue rate (zk_measure_rate(2): bare
+        # independent multiply-adds, as tools/ubench.hip) against the multiply-adds one mixed addition compiles to -- a figure read off
+        # the compiled code object, quoted only while profiles/static_counts.json belongs to the current sources
+        sc = static_counts()
+        if sc:
+            mpm = sc["mads_per_madd"]
+            alu["mad_floor"] = {"mads_per_madd": mpm, "floor_ms": madds * mpm / mad_rate * 1e3, "frac": (madds * mpm / mad_rate) / acc_s if acc_s > 0 else 0.0,
+                                "source": "profiles/static_counts.json", "arithmetic_source_sha256": sc["arithmetic_source_sha256"]}
         pmc = committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >")
         if pmc:
             alu["valu_issue_pmc"] = pmc

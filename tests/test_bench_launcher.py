@@ -122,3 +122,31 @@ def test_python_baseline_fit_and_labelled_extrapolation():
     assert 0.05 < noisy["max_rel_residual"] < 0.2
     host = mod.host_description()
     assert host["nproc"] == os.cpu_count() and (host["cpu_model"] is None or isinstance(host["cpu_model"], str))
+
+
+def test_static_figures_are_quoted_only_for_the_sources_they_came_from(tmp_path):
+    """roofline.alu.mad_floor (multiply-adds per addition, read off a code object) and valu_issue_pmc (a committed counter pass) are
+    not measured by a bench run: they carry the hash of the arithmetic sources they belong to and vanish when those change."""
+    import json
+    import shutil
+    mod = _load_bench()
+    sc = mod.static_counts()
+    assert sc is not None and sc["mads_per_madd"] > 1000 and sc["arithmetic_source_sha256"] == mod.arithmetic_source_hash()
+    # a copy of the tree with one changed byte in field.h: both figures are dropped
+    root = tmp_path / "repo"
+    csrc = root / "interactive-zkp-study_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for name in ("field.h", "curve.h", "msm_impl.h"):
+        shutil.copy(os.path.join(ROOT, "interactive-zkp-study_amd", "csrc", name), csrc / name)
+    shutil.copytree(os.path.join(ROOT, "profiles"), root / "profiles")
+    real = mod.ROOT
+    mod.ROOT = str(root)
+    try:
+        assert mod.static_counts() is not None
+        assert mod.committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >") is not None
+        with open(csrc / "field.h", "a") as f:
+            f.write("// changed\n")
+        assert mod.static_counts() is None
+        assert mod.committed_issue_rate("msm_accumulate_kernel<zk::Fe<zk::FpTag> >") is None
+    finally:
+        mod.ROOT = real

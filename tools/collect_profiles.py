@@ -53,6 +53,17 @@ def fold_sq(src, dst, rnd):
         k = short_name(r["Kernel_Name"])
         d = acc.setdefault(k, {}).setdefault(r["Dispatch_Id"], {})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    # the sources the counters belong to: bench.py quotes the issue rate only while they are unchanged
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_hash", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    with open(os.path.join(dst, rnd + "_pmc_sq_summary.meta.json"), "w") as f:
+        json.dump({"arithmetic_source_sha256": bench.arithmetic_source_hash()}, f, indent=1)
     with open(os.path.join(dst, rnd + "_pmc_sq_summary.csv"), "w") as f:
         f.write("kernel,dispatches," + ",".join(SQ_COUNTERS) + ",valu_insts_per_simd_cycle,active_valu_frac_of_wave_cycles,wait_inst_frac_of_wave_cycles\n")
         for k, disp in sorted(acc.items(), key=lambda kv: -sum(d.get("SQ_BUSY_CYCLES", 0) for d in kv[1].values())):
