@@ -67,11 +67,10 @@ def _worker(rank, world, port, n, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [1, 37])
-def test_sharded_msm_gloo_world2(n):
-    world = 2
-    port = 29500 + (os.getpid() % 2000) + n
+@pytest.mark.parametrize("world,n", [(2, 1), (2, 37), (8, 37)])   # 8 ranks: BASELINE.json configs[4]'s rank count, on the CPU
+def test_sharded_msm_gloo(world, n):
+    port = 29500 + (os.getpid() % 2000) + n + world
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, n, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}

@@ -69,7 +69,7 @@ def _worker(rank, world, port, log_n, l1, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,l1", [(2, 6, None), (2, 7, 3), (4, 8, None), (4, 7, 4)])
+@pytest.mark.parametrize("world,log_n,l1", [(2, 6, None), (2, 7, 3), (4, 8, None), (4, 7, 4), (8, 8, None)])   # 8: the driver's node size
 def test_dist_ntt_gloo(world, log_n, l1):
     port = 31500 + (os.getpid() % 2000) + 7 * log_n + world
     mgr = mp.Manager()
