@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--groth16-log-m", type=int, default=20, help="log2 constraints of the secondary Groth16 prove() timing (0 = skip)")
     ap.add_argument("--plonk-log-n", type=int, default=20, help="log2 gates of the secondary device-resident PLONK prove() timing (0 = skip)")
     ap.add_argument("--no-bound", action="store_true", help="skip the secondary bound-bases run (keeps a profiler's per-kernel averages to the headline workload)")
+    ap.add_argument("--no-facade", action="store_true", help="skip the secondary toy-size facade proofs (their small MSMs would enter a profiler's per-kernel averages)")
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--shard-total-log", type=int, default=26, help="N > 1 only: log2 points of the secondary ONE-MSM-sharded-over-all-GPUs "
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
@@ -696,7 +697,7 @@ def main():
 
     # ---- secondary: the reference-signature facade at the reference's own sizes (BASELINE.json configs[0]: toy Groth16 / PLONK proofs
     # through the host-buffer ABI, one library call per primitive; the entry points keep their plans)
-    if rank == 0 and world == 1 and not dist_on:
+    if rank == 0 and world == 1 and not dist_on and not args.no_facade:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_facade

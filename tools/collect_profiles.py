@@ -10,7 +10,7 @@ import argparse, csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SQ_COUNTERS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"]
-BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--sizes", "", "--sizes-ntt", ""]
+BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--no-facade", "--sizes", "", "--sizes-ntt", ""]
 
 
 def sh(cmd, log):
@@ -48,11 +48,15 @@ def fold_sq(src, dst, rnd):
     found = sorted(glob.glob(os.path.join(src, "pmc_SQ", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not found:
         return
-    acc = {}
+    acc, grid = {}, {}
     for r in csv.DictReader(open(found[-1])):
         k = short_name(r["Kernel_Name"])
         d = acc.setdefault(k, {}).setdefault(r["Dispatch_Id"], {})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        grid.setdefault(k, {})[r["Dispatch_Id"]] = int(r.get("Grid_Size", 0) or 0)
+    for k in acc:                                   # the headline workload's launches only: those with the kernel's largest grid
+        top = max(grid[k].values())
+        acc[k] = {i: v for i, v in acc[k].items() if grid[k][i] == top}
     # the sources the counters belong to: bench.py quotes the issue rate only while they are unchanged
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_for_hash", os.path.join(ROOT, "bench.py"))
@@ -95,8 +99,10 @@ def fold(rnd):
     # accumulate kernels together and each launch lasts twice as long; the launches of the TIMED steps are the last ones.
     traces = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     if traces:
-        d = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in csv.DictReader(open(traces[-1]))
-                   if "msm_accumulate_kernel" in r["Kernel_Name"] and "Fp2" not in r["Kernel_Name"])
+        rows_t = [r for r in csv.DictReader(open(traces[-1])) if "msm_accumulate_kernel" in r["Kernel_Name"] and "Fp2" not in r["Kernel_Name"]]
+        gsz = lambda r: int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+        top = max(gsz(r) for r in rows_t)
+        d = sorted((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in rows_t if gsz(r) == top)
         timed = [x[1] for x in d[-20:]]
         bl = json.loads(line)
         with open(os.path.join(dst, rnd + "_accumulate_launches.json"), "w") as f:
@@ -110,13 +116,17 @@ def fold(rnd):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         found = glob.glob(os.path.join(src, "pmc_" + ctr, "**", "*counter_collection.csv"), recursive=True)
         for path in sorted(found, key=os.path.getmtime)[-1:]:  # gpurun merges into gpurun_out/: keep the newest pass only
-            acc = {}
+            acc, grid = {}, {}
             for r in csv.DictReader(open(path)):
                 if r.get("Counter_Name") != ctr:
                     continue
                 k = short_name(r["Kernel_Name"])
                 a = acc.setdefault(k, {})
                 a[r["Dispatch_Id"]] = a.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+                grid.setdefault(k, {})[r["Dispatch_Id"]] = int(r.get("Grid_Size", 0) or 0)
+            for k in acc:                            # launches with the kernel's largest grid only
+                top = max(grid[k].values())
+                acc[k] = {i: v for i, v in acc[k].items() if grid[k][i] == top}
             for k, d in sorted(acc.items()):
                 avg = sum(d.values()) / len(d)
                 rows.append((k, ctr, len(d), avg))
