@@ -61,7 +61,7 @@ def test_twiddle_2d_kernel():
 
 
 @pytest.mark.parametrize("log_n,batch,log_block,big_log", [(1, 2, 0, 2), (4, 8, 2, 9), (6, 16, 3, 12), (8, 12, 8, 13), (10, 64, 7, 16), (11, 32, 9, 16), (12, 256, 10, 20),
-                                                           (13, 8, 5, 17), (16, 4, 14, 18)])
+                                                           (13, 8, 5, 17), (16, 4, 14, 18), (17, 4, 10, 19), (19, 2, 3, 20)])   # the last two: three-pass transforms
 def test_ntt_io_layouts_against_the_separate_passes(log_n, batch, log_block, big_log):
     """zk_ntt_dev_io: the four-step layouts read by the first loads / written by the last stores must give exactly what the
     separate passes give -- batched transform (zk_ntt_dev_batch), 2-D twiddle (zk_ntt_twiddle_dev) and a numpy permutation."""
