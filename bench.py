@@ -40,7 +40,7 @@ G1_BYTES_PER_POINT = 96  # 32 B scalar + 64 B affine point, each read once (SURV
 
 def arithmetic_source_hash():
     """SHA-256 over the sources that determine what one bucket addition compiles to: csrc/field.h, csrc/curve.h and the accumulate
-    kernel's text in csrc/msm_impl.h (sum_list .. msm_accumulate_kernel).  Figures that were NOT measured by this run but read off
+    kernel's text in csrc/msm_impl.h (between its [accumulate-kernel-begin] / -end markers).  Figures that were NOT measured by this run but read off
     a compiled code object or a committed counter pass (profiles/static_counts.json, profiles/*_pmc_sq_summary.csv) carry the hash of
     the sources they were taken from and are dropped from the line when it no longer matches."""
     import hashlib
@@ -49,8 +49,8 @@ def arithmetic_source_hash():
     for name in ("field.h", "curve.h"):
         h.update(open(os.path.join(csrc, name), "rb").read())
     text = open(os.path.join(csrc, "msm_impl.h")).read()
-    a, b = text.index("template <class F>\n__device__ __forceinline__ Xyzz<F> sum_list("), text.index("// Heavy buckets, stage 0")
-    h.update(text[a:b].encode())
+    a, b = text.find("// [accumulate-kernel-begin]"), text.find("// [accumulate-kernel-end]")
+    h.update((text[a:b] if 0 <= a < b else text).encode())     # markers gone: hash the whole file (nothing static is quoted then)
     return h.hexdigest()
 
 

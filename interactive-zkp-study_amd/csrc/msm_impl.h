@@ -281,11 +281,36 @@ __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *_
     __shared__ uint32_t stage_idx[NE];
     __shared__ uint8_t stage_loc[NE];
     __shared__ uint8_t stage_cell[NE];
+    __shared__ uint32_t cbase[MAX_CELLS];    // start of every cell's span: the exclusive scan of the (16-entry padded) cell totals
     const uint32_t t = threadIdx.x;
     const uint32_t i0 = blockIdx.x * NE + t;
     int nxt[PREP_PPT];
 #pragma unroll
     for (int rep = 0; rep < PREP_PPT; rep++) nxt[rep] = digits[i0 + rep * PREP_NT];
+    {
+        // Every workgroup scans the <= 2048 cell totals of the prepare kernel for itself (8 KB of loads) instead of waiting for a
+        // one-workgroup scan kernel between the two: one dependent launch less on the lane's stream.  Workgroup 0 publishes the result
+        // for the cell sort; the counters are zeroed for the next run by msm_segcount_kernel (after every partition workgroup has read
+        // them).  Cell spans start on 16-entry boundaries so the cell sort can fetch 16 entries per load.
+        const uint32_t ncells = W * G;
+        const uint32_t v0 = 2 * t < ncells ? B.cell_total[2 * t] : 0u, v1 = 2 * t + 1 < ncells ? B.cell_total[2 * t + 1] : 0u;
+        const uint32_t p0 = (v0 + 15u) & ~15u, p1 = (v1 + 15u) & ~15u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<PREP_NT>(p0 + p1, wave_tot, &total);
+        cbase[2 * t] = ex;
+        cbase[2 * t + 1] = ex + p0;
+        if (blockIdx.x == 0) {
+            if (2 * t < ncells) {
+                B.cell_base[2 * t] = ex;
+                B.cell_cnt[2 * t] = v0;
+            }
+            if (2 * t + 1 < ncells) {
+                B.cell_base[2 * t + 1] = ex + p0;
+                B.cell_cnt[2 * t + 1] = v1;
+            }
+        }
+        __syncthreads();
+    }
     for (uint32_t w = 0; w < W; w++) {
         if (t < 128) hist[t] = 0;
         __syncthreads();
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *_
         const uint32_t ex = block_exclusive_scan<PREP_NT>(h, wave_tot, &total);
         if (t < 128) {
             hist[t] = ex;
-            gpos[t] = (h && t < G) ? B.cell_base[w * G + t] + atomicAdd(&B.cell_cursor[w * G + t], h) : 0u;
+            gpos[t] = (h && t < G) ? cbase[w * G + t] + atomicAdd(&B.cell_cursor[w * G + t], h) : 0u;
         }
         __syncthreads();
 #pragma unroll
@@ -338,6 +363,10 @@ __global__ __launch_bounds__(SEG_NT) void msm_segcount_kernel(SortBufs B) {
     const uint32_t cellid = w * G + g;
     const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
     const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
+    if (z == 0 && t == 0) {   // every partition workgroup is done with them (stream order): ready for the next run's prepare / partition
+        B.cell_total[cellid] = 0;
+        B.cell_cursor[cellid] = 0;
+    }
     if (z >= nchunks) return;
     const uint8_t *__restrict__ loc = B.e_loc + seg0;
     hist[t] = 0;
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint
 
 // grid covers the flattened bucket array, 2 buckets per thread: ranks the buckets by list length
 // (workgroup-local LDS histogram, one global reservation per non-empty length bin) and registers
-// heavy buckets (their segment tasks are written by msm_heavy_expand_kernel).
+// heavy buckets together with their wavefront tasks (summed by msm_heavy_kernel).
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbuckets) {
     __shared__ uint32_t hist[SIZE_BINS];
@@ -474,8 +503,12 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbu
                 const uint32_t tpos = atomicAdd(&B.heavy_ctr[0], nseg);
                 const uint32_t hb = atomicAdd(&B.heavy_ctr[1], 1u);
                 // capacity is sized so this always holds; if it ever does not, the submission fails at collect
-                if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) B.heavy_buckets[hb] = make_uint4(b0i + q, tpos, nseg, 0u);
-                else atomicAdd(B.err, 1u);
+                if (tpos + nseg <= B.heavy_cap && hb < B.heavy_cap) {
+                    B.heavy_buckets[hb] = make_uint4(b0i + q, tpos, nseg, 0u);   // .w: wavefront tasks of this bucket that have finished
+                    for (uint32_t k = 0; k < nseg; k++) B.heavy_tasks[tpos + k] = make_uint2(hb, k);   // (heavy-bucket slot, 64-segment group)
+                } else {
+                    atomicAdd(B.err, 1u);
+                }
             }
         }
     }
@@ -494,6 +527,7 @@ __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbu
 // length (perm[]): the 64 lanes of a wavefront own lists of (nearly) equal length, wavefronts retire
 // independently and the longest lists start first.  Each thread adds its points in XYZZ mixed
 // coordinates (8M+2S per point).
+// [accumulate-kernel-begin]  (bench.py hashes field.h, curve.h and the text between these two markers: arithmetic_source_hash)
 template <class F>
 __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ lst, uint32_t len) {
     // No software prefetch: holding the next point would cost the registers that let four (G1) / two (G2) wavefronts
@@ -528,16 +562,7 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumul
     if (len > heavy_th) return;  // summed by the heavy kernels
     buckets[b] = sum_list(pts, sorted + bucket_off[b], len);
 }
-
-// Heavy buckets, stage 0: write the (bucket, segment) task list, one workgroup per heavy bucket at a time.
-template <int DUMMY>
-__global__ __launch_bounds__(256) void msm_heavy_expand_kernel(SortBufs B) {
-    const uint32_t nheavy = min(B.heavy_ctr[1], B.heavy_cap);
-    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const uint4 hb = B.heavy_buckets[h];
-        for (uint32_t k = threadIdx.x; k < hb.z; k += 256) B.heavy_tasks[hb.y + k] = make_uint2(hb.x, k);
-    }
-}
+// [accumulate-kernel-end]
 
 template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
     Xyzz<F> r;
@@ -548,36 +573,42 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<
     for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
     return r;
 }
-// Heavy buckets, stage 1: one wavefront per task = 64 consecutive HEAVY_SEG-entry segments of one bucket's
-// list; every lane sums its segment, a __shfl tree leaves the task's partial sum in lane 0.
+// Heavy buckets (lists longer than heavy_th: skewed / witness-like scalars), ONE launch of one-wavefront workgroups; msm_rank_kernel has
+// written the task list.  A task = 64 consecutive HEAVY_SEG-entry segments of one bucket's list: every lane sums its segment, a __shfl
+// tree leaves the task's partial sum in lane 0, which stores it and counts the task as finished on its bucket; the wavefront that
+// finishes a bucket's LAST task then sums that bucket's partials (stride-64 serial sums, __shfl tree) into the bucket array.  With
+// uniform scalars there are no tasks and every workgroup returns at once -- one nearly empty launch on the lane's stream where there
+// used to be three (expand, segments, combine), each of which waited its turn behind the neighbouring lanes' accumulate kernels.
+// Hand-off of the partials between wavefronts: plain stores, s_waitcnt, agent-scope release, relaxed agent-scope counter; the last
+// arriver acquires at agent scope before it loads (MI355X_MICROARCH.md, inter-workgroup visibility).
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_heavy_segments_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B,
-                                                                                            Xyzz<F> *__restrict__ partial) {
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_heavy_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B, Xyzz<F> *partial,
+                                                                                   Xyzz<F> *__restrict__ buckets) {
     const uint32_t ntasks = min(B.heavy_ctr[0], B.heavy_cap), lane = threadIdx.x;
     for (uint32_t wt = blockIdx.x; wt < ntasks; wt += gridDim.x) {
         const uint2 task = B.heavy_tasks[wt];
-        const uint32_t len = B.counts[task.x], lo = (task.y * 64 + lane) * HEAVY_SEG;
-        Xyzz<F> acc = sum_list(pts, B.sorted + B.bucket_off[task.x] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u);
+        const uint4 hb = B.heavy_buckets[task.x];   // (bucket id, first task, tasks, -)
+        const uint32_t len = B.counts[hb.x], lo = (task.y * 64 + lane) * HEAVY_SEG;
+        Xyzz<F> acc = sum_list(pts, B.sorted + B.bucket_off[hb.x] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u);
 #pragma unroll 1
         for (int d = 32; d >= 1; d >>= 1) {
             const Xyzz<F> o = shfl_down_xyzz(acc, d);
             xyzz_add(acc, o);
         }
-        if (lane == 0) partial[wt] = acc;
-    }
-}
-
-// Heavy buckets, stage 2: one 512-thread workgroup per bucket; threads sum the partials serially with
-// stride 512, then a wavefront __shfl tree, an 8-entry LDS exchange and a second tree in wavefront 0.
-constexpr int HEAVY_CT = 512;
-template <class F>
-__global__ __launch_bounds__(HEAVY_CT) void msm_heavy_combine_kernel(SortBufs B, const Xyzz<F> *__restrict__ partial, Xyzz<F> *__restrict__ buckets) {
-    __shared__ Xyzz<F> wave_sum[HEAVY_CT / 64];
-    const uint32_t nheavy = min(B.heavy_ctr[1], B.heavy_cap), t = threadIdx.x;
-    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const uint4 hb = B.heavy_buckets[h];
-        Xyzz<F> acc = Xyzz<F>::inf();
-        for (uint32_t k = t; k < hb.z; k += HEAVY_CT) {
+        uint32_t done = 0;
+        if (lane == 0) {
+            partial[wt] = acc;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the fence's own wait (MI355X_MICROARCH.md, compiler hazard)
+            done = __hip_atomic_fetch_add(&B.heavy_buckets[task.x].w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        }
+        done = __shfl(done, 0, 64);
+        if (done != hb.z) continue;                 // other tasks of this bucket are still running: their last one combines
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc = Xyzz<F>::inf();
+        for (uint32_t k = lane; k < hb.z; k += 64) {
             const Xyzz<F> v = partial[hb.y + k];
             xyzz_add(acc, v);
         }
@@ -586,18 +617,7 @@ __global__ __launch_bounds__(HEAVY_CT) void msm_heavy_combine_kernel(SortBufs B,
             const Xyzz<F> o = shfl_down_xyzz(acc, d);
             xyzz_add(acc, o);
         }
-        if ((t & 63) == 0) wave_sum[t >> 6] = acc;
-        __syncthreads();
-        if (t < 64) {
-            acc = t < HEAVY_CT / 64 ? wave_sum[t] : Xyzz<F>::inf();
-#pragma unroll 1
-            for (int d = HEAVY_CT / 128; d >= 1; d >>= 1) {
-                const Xyzz<F> o = shfl_down_xyzz(acc, d);
-                xyzz_add(acc, o);
-            }
-            if (t == 0) buckets[hb.x] = acc;
-        }
-        __syncthreads();
+        if (lane == 0) buckets[hb.x] = acc;
     }
 }
 
@@ -930,9 +950,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         SortBufs B = sort_bufs(L);
         B.heavy_th = std::max<uint32_t>(32, 8 * (n_pad / nb));
         const uint32_t nbuckets_all = W * nb;
-        hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B, n_pad, W,
-                           G);
+                           G);   // scans the cell totals itself
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B, nb);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
@@ -944,13 +963,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                            L.sorted.template as<uint32_t>(), L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(),
                            L.perm.template as<uint32_t>(), L.arena.template as<Xyzz<F>>(), nbuckets, B.heavy_th);
         mark(L, 6);
-        // heavy buckets (normally none): the grids cover the worst case and exit on the device-side counters.  Same stream:
+        // heavy buckets (normally none): one launch whose workgroups return at once when msm_rank_kernel registered no task.  Same stream:
         // a lane's low-occupancy phases are filled by the neighbouring lanes, and the device only has a few hardware queues.
-        hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, st, B);
-        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, st,
-                           L.pts_m.template as<PackedAffine<F>>(), B, L.heavy_partial.template as<Xyzz<F>>());
-        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, st, B, L.heavy_partial.template as<Xyzz<F>>(),
-                           L.arena.template as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_heavy_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 4)), dim3(64), 0, st, L.pts_m.template as<PackedAffine<F>>(), B,
+                           L.heavy_partial.template as<Xyzz<F>>(), L.arena.template as<Xyzz<F>>());
     }
 
     // Enqueues the whole GPU pipeline plus the 36 KiB read-back; returns a ticket.  The work runs on the lane's own
@@ -1034,10 +1050,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                            L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(), L.perm.template as<uint32_t>(),
                            L.arena.template as<Xyzz<F>>(), FIX_NB, B.heavy_th);
         mark(L, 6);
-        hipLaunchKernelGGL((msm_heavy_expand_kernel<0>), dim3(64), dim3(256), 0, ls, B);
-        hipLaunchKernelGGL((msm_heavy_segments_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 8)), dim3(64), 0, ls, table, B,
-                           L.heavy_partial.template as<Xyzz<F>>());
-        hipLaunchKernelGGL((msm_heavy_combine_kernel<F>), dim3(64), dim3(HEAVY_CT), 0, ls, B, L.heavy_partial.template as<Xyzz<F>>(),
+        hipLaunchKernelGGL((msm_heavy_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 4)), dim3(64), 0, ls, table, B, L.heavy_partial.template as<Xyzz<F>>(),
                            L.arena.template as<Xyzz<F>>());
         mark(L, 3);
         const uint32_t levels = FIX_C - 1, BL = 9;
