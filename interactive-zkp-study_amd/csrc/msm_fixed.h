@@ -145,6 +145,22 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
     __shared__ uint8_t stage_loc[NE];
     const uint32_t t = threadIdx.x;
     const uint32_t v0 = blockIdx.x * NE;
+    // span starts of this thread's two cells: every workgroup scans the 2048 cell totals of the prepare kernel itself (no scan launch
+    // in between; workgroup 0 publishes them for the cell sort, msm_segcount_kernel zeroes the counters for the next run)
+    uint32_t cb0, cb1;
+    {
+        const uint32_t c0 = B.cell_total[2 * t], c1 = B.cell_total[2 * t + 1];
+        const uint32_t p0 = (c0 + 15u) & ~15u, p1 = (c1 + 15u) & ~15u;   // 16-entry aligned spans (the cell sort fetches 16 entries per load)
+        uint32_t all;
+        cb0 = block_exclusive_scan<PREP_NT>(p0 + p1, wave_tot, &all);
+        cb1 = cb0 + p0;
+        if (blockIdx.x == 0) {
+            B.cell_base[2 * t] = cb0;
+            B.cell_cnt[2 * t] = c0;
+            B.cell_base[2 * t + 1] = cb1;
+            B.cell_cnt[2 * t + 1] = c1;
+        }
+    }
     for (uint32_t k = t; k < FIX_G; k += PREP_NT) hist[k] = 0;
     __syncthreads();
     uint32_t rk[PPT], jj[PPT];
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
     const uint32_t ex = block_exclusive_scan<PREP_NT>(h0 + h1, wave_tot, &total_here);
     hist[2 * t] = ex;
     hist[2 * t + 1] = ex + h0;
-    gpos[2 * t] = h0 ? B.cell_base[2 * t] + atomicAdd(&B.cell_cursor[2 * t], h0) : 0u;
-    gpos[2 * t + 1] = h1 ? B.cell_base[2 * t + 1] + atomicAdd(&B.cell_cursor[2 * t + 1], h1) : 0u;
+    gpos[2 * t] = h0 ? cb0 + atomicAdd(&B.cell_cursor[2 * t], h0) : 0u;
+    gpos[2 * t + 1] = h1 ? cb1 + atomicAdd(&B.cell_cursor[2 * t + 1], h1) : 0u;
     __syncthreads();
 #pragma unroll
     for (int rep = 0; rep < PPT; rep++) {

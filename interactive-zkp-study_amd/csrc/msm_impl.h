@@ -120,10 +120,10 @@ constexpr int HEAVY_WAVE = 64 * HEAVY_SEG;  // entries per wavefront task
 struct SortBufs {
     uint32_t *counts;       // [W*nb]   list length of every bucket
     uint32_t *bucket_off;   // [W*nb]   start of every bucket's list inside sorted[]
-    uint32_t *cell_total;   // [cells]  entries per cell; accumulated by prepare, zeroed by the scan kernel
-    uint32_t *cell_base;    // [cells]  exclusive scan of cell_total
+    uint32_t *cell_total;   // [cells]  entries per cell; accumulated by prepare, zeroed by msm_segcount_kernel
+    uint32_t *cell_base;    // [cells]  exclusive scan of the padded cell_total (published by partition workgroup 0)
     uint32_t *cell_cnt;     // [cells]  copy of cell_total for the later passes
-    uint32_t *cell_cursor;  // [cells]  partition write cursors (zeroed by the scan kernel)
+    uint32_t *cell_cursor;  // [cells]  partition write cursors (zeroed by msm_segcount_kernel)
     uint32_t *e_idx;        // [W*n]    partitioned entries: point index | sign << 31
     uint8_t *e_loc;         // [W*n]    partitioned entries: bucket index inside the cell
     uint32_t *sorted;       // [W*n]    entries grouped by bucket
@@ -230,42 +230,22 @@ __global__ __launch_bounds__(PREP_NT) void msm_prepare_kernel(const uint32_t *__
     }
 }
 
-// One workgroup.  SIZES == false (after prepare): exclusive scan of the (<= 2048) cell totals ->
-// cell_base / cell_cnt.  SIZES == true (after segsort): exclusive scan of the list-length histogram
-// in DEcreasing length order (rank 0 = longest lists).  Each leaves the counters it consumed zeroed
-// for the next run (they start zeroed at plan creation).
+// One workgroup, after the cell sort: exclusive scan of the list-length histogram in DEcreasing length order (rank 0 = longest
+// lists).  Leaves the counters it consumed zeroed for the next run (they start zeroed at plan creation).  (The scan of the cell
+// totals between prepare and partition was a launch of its own until round 3; the partition kernels do it themselves now.)
 template <bool SIZES>
 __global__ __launch_bounds__(1024) void msm_scan_kernel(SortBufs B, uint32_t ncells) {
+    static_assert(SIZES, "only the list-length scan is a kernel of its own");
     __shared__ uint32_t wave_tot[1024 / 64 + 1];
     const uint32_t t = threadIdx.x;
     uint32_t total;
-    if (!SIZES) {
-        const uint32_t v0 = 2 * t < ncells ? B.cell_total[2 * t] : 0u;
-        const uint32_t v1 = 2 * t + 1 < ncells ? B.cell_total[2 * t + 1] : 0u;
-        // cell spans start on 16-entry boundaries so the cell sort can fetch 16 entries per load
-        const uint32_t p0 = (v0 + 15u) & ~15u, p1 = (v1 + 15u) & ~15u;
-        const uint32_t ex = block_exclusive_scan<1024>(p0 + p1, wave_tot, &total);
-        if (2 * t < ncells) {
-            B.cell_base[2 * t] = ex;
-            B.cell_cnt[2 * t] = v0;
-            B.cell_total[2 * t] = 0;
-            B.cell_cursor[2 * t] = 0;
-        }
-        if (2 * t + 1 < ncells) {
-            B.cell_base[2 * t + 1] = ex + p0;
-            B.cell_cnt[2 * t + 1] = v1;
-            B.cell_total[2 * t + 1] = 0;
-            B.cell_cursor[2 * t + 1] = 0;
-        }
-    } else {
-        const uint32_t bin = SIZE_BINS - 1u - t;  // thread 0 takes the longest lists
-        const uint32_t hv = B.size_hist[bin];
-        const uint32_t hx = block_exclusive_scan<1024>(hv, wave_tot, &total);
-        B.size_base[bin] = hx;
-        B.size_hist[bin] = 0;
-        B.size_cursor[bin] = 0;
-        if (t < 2) B.heavy_ctr[t] = 0;
-    }
+    const uint32_t bin = SIZE_BINS - 1u - t;  // thread 0 takes the longest lists
+    const uint32_t hv = B.size_hist[bin];
+    const uint32_t hx = block_exclusive_scan<1024>(hv, wave_tot, &total);
+    B.size_base[bin] = hx;
+    B.size_hist[bin] = 0;
+    B.size_cursor[bin] = 0;
+    if (t < 2) B.heavy_ctr[t] = 0;
 }
 
 // One workgroup = 4096 points.  Window by window: rank the 4096 digits by cell in LDS (LDS-atomic
@@ -1035,7 +1015,6 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         SortBufs B = sort_bufs(L);
         B.heavy_th = std::max<uint32_t>(32, 8 * (uint32_t)(((size_t)FIX_W * n_pad) / FIX_NB));
         const PackedAffine<F> *table = fix_table.template as<PackedAffine<F>>();
-        hipLaunchKernelGGL((msm_scan_kernel<false>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
         constexpr int FIX_PPT = 8;
         const uint32_t fix_total = (uint32_t)FIX_W * n_pad;
         hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
