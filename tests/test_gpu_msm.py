@@ -220,7 +220,7 @@ def test_g1_msm_2pow16_bit_exact():
     assert np.array_equal(msm_g1(S, Pts), oracle_g1(S, Pts))
 
 
-@pytest.mark.parametrize("pattern", ["witness_like", "all_equal", "two_values", "minus_one_heavy"])
+@pytest.mark.parametrize("pattern", ["witness_like", "all_equal", "two_values", "minus_one_heavy", "forty_values"])
 def test_g1_msm_skewed_scalars_large(pattern):
     """Hot digits at 2^18 points: cells far larger than one workgroup's share and buckets with up to n entries
     (multi-workgroup cell sort, heavy-bucket wavefront tasks) -- bit-exact against the oracle's serial bucket MSM."""
@@ -241,9 +241,22 @@ def test_g1_msm_skewed_scalars_large(pattern):
     elif pattern == "two_values":
         S[pick < 0.5] = S[0]
         S[pick >= 0.5] = S[1]
+    elif pattern == "forty_values":       # ~40 heavy buckets in every window, several wavefront tasks each: many per-bucket combines at once
+        S = S[rng.integers(0, 40, size=n)]
     else:
         S[pick < 0.7] = limb_row(o.R - 1)
-    assert np.array_equal(msm_g1(S, Pts), co.g1_msm_bucket_arr(S, Pts, 14))
+    want = co.g1_msm_bucket_arr(S, Pts, 14)
+    assert np.array_equal(msm_g1(S, Pts), want)
+    if pattern in ("forty_values", "witness_like"):
+        # the same with three submissions in flight (the heavy-bucket kernel of one lane beside the others' accumulate kernels)
+        import torch
+        dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        plan = MsmPlan(_lib.GROUP_G1, n)
+        tickets = [plan.submit(dS.data_ptr(), dP.data_ptr(), n, st) for _ in range(3)]
+        for t in tickets:
+            assert np.array_equal(plan.collect_limbs(t)[0], want)
+        plan.close()
 
 
 @pytest.mark.parametrize("n", [131072, 131073, 300001])

@@ -49,13 +49,15 @@ def main():
         for j in range(int(rng.integers(1, 5))):
             m = n if rng.random() < 0.5 else int(rng.integers(0, n + 1))
             S = random_scalars(rng, max(m, 1))[:m]
-            pat = rng.integers(0, 4)
+            pat = rng.integers(0, 5)
             if m and pat == 1:
                 S[rng.random(m) < 0.5] = np.array([1, 0, 0, 0], dtype=np.uint64)
             elif m and pat == 2:
                 S[:] = S[0]
             elif m and pat == 3:
                 S[rng.random(m) < 0.3] = 0
+            elif m and pat == 4:               # a handful of distinct scalars: several heavy buckets in every window at once
+                S = S[rng.integers(0, min(m, int(rng.integers(2, 65))), size=m)]
             jobs.append((m, S, torch.from_numpy(np.ascontiguousarray(S).view(np.int64)).cuda()))
         pend, res = [], []
         for m, S, dS in jobs:
