@@ -292,6 +292,10 @@ static thread_local std::map<std::pair<int, int>, std::vector<std::unique_ptr<Ho
 static thread_local std::map<std::pair<int, unsigned>, std::unique_ptr<HostNttCtx>> g_ntt_cache;            // (device, log_n)
 static thread_local uint64_t g_cache_clock = 0;
 constexpr size_t MSM_CACHE_PER_GROUP = 3, NTT_CACHE_PLANS = 6;
+// Calls beyond these sizes build their plan for the call and release it afterwards: a one-off 2^26-point host-buffer MSM must not
+// leave 10 GB of staging buffer and workspace behind in the calling thread.
+constexpr size_t MSM_CACHE_MAX_POINTS = (size_t)1 << 24;
+constexpr unsigned NTT_CACHE_MAX_LOG = 24;
 
 static HostMsmCtx &host_msm_ctx(int group, size_t n, size_t point_bytes) {
     int dev = 0;
@@ -352,7 +356,14 @@ template <class F> static int msm_host(int group, const uint64_t *scalars, const
         return ZK_OK;
     }
     if (!scalars_canonical(scalars, n)) return invalid("zk_msm: scalar not canonical (>= r)");
-    HostMsmCtx &ctx = host_msm_ctx(group, n, PB);
+    std::unique_ptr<HostMsmCtx> once;
+    if (n > MSM_CACHE_MAX_POINTS) {
+        once.reset(new HostMsmCtx);
+        once->plan.reset(msm_plan_new(group, n));
+        once->in.alloc(n * (32 + PB));
+        g_cache_stats.msm_builds++;
+    }
+    HostMsmCtx &ctx = once ? *once : host_msm_ctx(group, n, PB);
     char *ds = ctx.in.as<char>(), *dp = ds + n * 32;
     ZK_HIP(hipMemcpy(ds, scalars, n * 32, hipMemcpyHostToDevice));
     ZK_HIP(hipMemcpy(dp, points, n * PB, hipMemcpyHostToDevice));
@@ -633,7 +644,14 @@ int zk_ntt_fr(uint64_t *data, unsigned log_n, int inverse, const uint64_t coset_
         const size_t n = (size_t)1 << log_n;
         if (!scalars_canonical(data, n)) return invalid("zk_ntt_fr: element not canonical (>= r)");
         if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_fr: coset_shift must be a canonical non-zero element of F_r");
-        HostNttCtx &ctx = host_ntt_ctx(log_n);   // plan (tables) + staging buffer of this size, built once per thread and device
+        std::unique_ptr<HostNttCtx> once;
+        if (log_n > NTT_CACHE_MAX_LOG) {
+            once.reset(new HostNttCtx);
+            once->plan.reset(new NttPlan(log_n));
+            once->buf.alloc(n * 32);
+            g_cache_stats.ntt_builds++;
+        }
+        HostNttCtx &ctx = once ? *once : host_ntt_ctx(log_n);   // plan (tables) + staging buffer of this size, built once per thread and device
         ZK_HIP(hipMemcpy(ctx.buf.p, data, n * 32, hipMemcpyHostToDevice));
         ctx.plan->run(ctx.buf.p, inverse != 0, coset_shift, 0);
         ZK_HIP(hipStreamSynchronize(0));
