@@ -114,6 +114,9 @@ constexpr int SEG_EPT = 16;  // entries per thread per chunk
 constexpr int SEG_CHUNK = SEG_NT * SEG_EPT;
 constexpr int SIZE_BINS = 1024;  // list lengths >= SIZE_BINS-1 share the top bin
 constexpr int SEG_Z = 8;         // workgroups sharing one cell (they split its chunks round-robin)
+constexpr int CS_NT = 512;       // single-workgroup cell sort: threads,
+constexpr int CS_EPT = 20;       //   entries per thread (five 16-byte loads),
+constexpr int CS_MAX = CS_NT * CS_EPT;   // and the largest cell it takes (10240 entries; uniform 2^20-point MSMs have 8192 +- 90 per cell)
 constexpr int HEAVY_SEG = 32;    // entries per heavy-bucket segment (one thread each)
 constexpr int HEAVY_WAVE = 64 * HEAVY_SEG;  // entries per wavefront task
 
@@ -333,7 +336,81 @@ __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *_
     }
 }
 
-// Cell sort, grid = (SEG_Z, G, W): up to SEG_Z workgroups share a cell and take its 4096-entry chunks
+// Cell sort, common case, grid = (G, W): ONE workgroup sorts a whole cell of up to CS_MAX entries in a single pass -- every thread
+// keeps its 20 entries in registers (16-byte loads: cell spans are 16-entry aligned), ranks them with LDS atomics on the 256 bucket
+// counters, the counters are scanned (-> counts, bucket_off, list-length histogram), the entries are placed in an LDS image of the
+// sorted cell and that image is written out in order: one read and one fully coalesced write of the cell, no per-workgroup count
+// table, no second kernel.  Larger cells (MSMs beyond ~1.2 M entries per window, hot digits of skewed scalars) are left to the
+// multi-workgroup pair below, which skips the cells done here.  Also zeroes the cell's partition counters for the next run (every
+// partition workgroup is done with them: stream order).
+template <int DUMMY>
+__global__ __launch_bounds__(CS_NT) void msm_cellsort_kernel(SortBufs B, uint32_t nb) {
+    __shared__ uint32_t cnt[SEG_BUCKETS];   // entries per bucket, then exclusive offsets
+    __shared__ uint32_t hist[SIZE_BINS];
+    __shared__ uint32_t wave_tot[CS_NT / 64 + 1];
+    __shared__ uint32_t img[CS_MAX];        // the sorted cell
+    const uint32_t t = threadIdx.x, g = blockIdx.x, w = blockIdx.y, G = gridDim.x;
+    const uint32_t cellid = w * G + g;
+    const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
+    if (t == 0) {
+        B.cell_total[cellid] = 0;
+        B.cell_cursor[cellid] = 0;
+    }
+    if (seg_n > CS_MAX) return;
+    const uint32_t base = g * SEG_BUCKETS;
+    const uint32_t nloc = min((uint32_t)SEG_BUCKETS, nb - base);
+    const size_t flat0 = (size_t)w * nb + base;
+    if (t < SEG_BUCKETS) cnt[t] = 0;
+    for (uint32_t k = t; k < SIZE_BINS; k += CS_NT) hist[k] = 0;
+    __syncthreads();
+    // slab s holds entries s * 4 * CS_NT + 4 t .. + 3 of thread t: consecutive threads, consecutive 16-byte pieces
+    constexpr int SLABS = CS_EPT / 4;
+    uint32_t e_i[CS_EPT], e_r[CS_EPT];
+    uint32_t e_l[SLABS];                     // four bucket bytes per slab
+    const uint8_t *__restrict__ loc = B.e_loc + seg0;
+    const uint32_t *__restrict__ idx = B.e_idx + seg0;
+#pragma unroll
+    for (int sl = 0; sl < SLABS; sl++) {
+        const uint32_t e0 = (uint32_t)sl * 4 * CS_NT + 4 * t;
+        e_l[sl] = 0;
+        if (e0 < seg_n) {
+            const uint4 iv = *reinterpret_cast<const uint4 *>(idx + e0);
+            e_l[sl] = *reinterpret_cast<const uint32_t *>(loc + e0);
+            e_i[4 * sl] = iv.x; e_i[4 * sl + 1] = iv.y; e_i[4 * sl + 2] = iv.z; e_i[4 * sl + 3] = iv.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CS_EPT; k++) {
+        const uint32_t e = (uint32_t)(k >> 2) * 4 * CS_NT + 4 * t + (k & 3);
+        if (e < seg_n) e_r[k] = atomicAdd(&cnt[(e_l[k >> 2] >> (8 * (k & 3))) & 0xffu], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = t < SEG_BUCKETS ? cnt[t] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<CS_NT>(c, wave_tot, &total);
+    if (t < SEG_BUCKETS) cnt[t] = ex;
+    if (t < nloc) {
+        B.counts[flat0 + t] = c;
+        B.bucket_off[flat0 + t] = seg0 + ex;
+        atomicAdd(&hist[size_bin(c, B.heavy_th)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = t; k < SIZE_BINS; k += CS_NT) {
+        const uint32_t h = hist[k];
+        if (h) atomicAdd(&B.size_hist[k], h);
+    }
+#pragma unroll
+    for (int k = 0; k < CS_EPT; k++) {
+        const uint32_t e = (uint32_t)(k >> 2) * 4 * CS_NT + 4 * t + (k & 3);
+        if (e < seg_n) img[cnt[(e_l[k >> 2] >> (8 * (k & 3))) & 0xffu] + e_r[k]] = e_i[k];
+    }
+    __syncthreads();
+    uint32_t *__restrict__ sorted = B.sorted + seg0;   // 16-entry aligned span; the padding behind seg_n is never read
+    for (uint32_t e0 = 4 * t; e0 < seg_n; e0 += 4 * CS_NT)
+        *reinterpret_cast<uint4 *>(sorted + e0) = make_uint4(img[e0], img[e0 + 1], img[e0 + 2], img[e0 + 3]);
+}
+
+// Cell sort, large cells, grid = (SEG_Z, G, W): up to SEG_Z workgroups share a cell and take its 4096-entry chunks
 // round-robin, so a cell swollen by skewed scalars (a hot digit) is still sorted by several CUs.
 // Kernel 1 counts: zcount[cell][z][b] = entries of bucket b in the chunks of workgroup z.
 template <int DUMMY>
@@ -343,11 +420,7 @@ __global__ __launch_bounds__(SEG_NT) void msm_segcount_kernel(SortBufs B) {
     const uint32_t cellid = w * G + g;
     const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
     const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
-    if (z == 0 && t == 0) {   // every partition workgroup is done with them (stream order): ready for the next run's prepare / partition
-        B.cell_total[cellid] = 0;
-        B.cell_cursor[cellid] = 0;
-    }
-    if (z >= nchunks) return;
+    if (seg_n <= CS_MAX || z >= nchunks) return;   // small cells were sorted by msm_cellsort_kernel
     const uint8_t *__restrict__ loc = B.e_loc + seg0;
     hist[t] = 0;
     __syncthreads();
@@ -385,7 +458,7 @@ __global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint
     const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
     const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
     const uint32_t active = min((uint32_t)SEG_Z, nchunks);
-    if (z >= max(active, 1u)) return;  // workgroup 0 always runs: empty cells still publish their zero counts
+    if (seg_n <= CS_MAX || z >= active) return;   // small (and empty) cells were sorted and published by msm_cellsort_kernel
     const uint8_t *__restrict__ loc = B.e_loc + seg0;
     const uint32_t *__restrict__ idx = B.e_idx + seg0;
     uint32_t *__restrict__ sorted = B.sorted;
@@ -932,6 +1005,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const uint32_t nbuckets_all = W * nb;
         hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B, n_pad, W,
                            G);   // scans the cell totals itself
+        hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(G, W), dim3(CS_NT), 0, st, B, nb);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B, nb);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
@@ -1019,6 +1093,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const uint32_t fix_total = (uint32_t)FIX_W * n_pad;
         hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
                            L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total);
+        hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(FIX_G, 1), dim3(CS_NT), 0, ls, B, FIX_NB);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B, FIX_NB);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
