@@ -251,88 +251,80 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(SortBufs B, uint32_t nce
     if (t < 2) B.heavy_ctr[t] = 0;
 }
 
-// One workgroup = 4096 points.  Window by window: rank the 4096 digits by cell in LDS (LDS-atomic
-// ranks + block scan), reserve the cells' global spans (one atomic per non-empty cell), stage the
-// entries in cell order and write them out with consecutive lanes on consecutive addresses.
+// Coarse radix pass, grid = (n_pad / 8192, W): one workgroup takes 8192 consecutive digits of ONE window (16 KB, read with 16-byte
+// loads), ranks them by cell in LDS (LDS-atomic ranks + block scan), reserves the cells' global spans (one atomic per non-empty cell),
+// stages the entries in cell order and writes them out with consecutive lanes on consecutive addresses: runs of 8192 / G = 64 entries
+// per cell.  (Until round 3 a workgroup walked all W windows of 4096 points, seven barriers of a 1024-thread workgroup per window:
+// 81 us for 2^20 points where the traffic needs 40.)  The start of every cell's span is the exclusive scan of the 16-entry padded
+// cell totals of the prepare kernel, which every workgroup computes for its window itself (no scan launch between the two kernels);
+// the first workgroup of a window publishes it for the cell sort.
+constexpr int PART_PTS = 8192;
 template <int DUMMY>
 __global__ __launch_bounds__(PREP_NT) void msm_partition_kernel(const int16_t *__restrict__ digits, SortBufs B, uint32_t n_pad, uint32_t W,
                                                                 uint32_t G) {
-    constexpr int NE = PREP_NT * PREP_PPT;  // entries per window per workgroup
+    constexpr int EPT = PART_PTS / PREP_NT;  // 8 entries per thread
     __shared__ uint32_t hist[128];           // G <= 128 cells per window: counts, then exclusive offsets
     __shared__ uint32_t gpos[128];           // global position of this workgroup's span in every cell
     __shared__ uint32_t wave_tot[PREP_NT / 64 + 1];
-    __shared__ uint32_t stage_idx[NE];
-    __shared__ uint8_t stage_loc[NE];
-    __shared__ uint8_t stage_cell[NE];
-    __shared__ uint32_t cbase[MAX_CELLS];    // start of every cell's span: the exclusive scan of the (16-entry padded) cell totals
-    const uint32_t t = threadIdx.x;
-    const uint32_t i0 = blockIdx.x * NE + t;
-    int nxt[PREP_PPT];
-#pragma unroll
-    for (int rep = 0; rep < PREP_PPT; rep++) nxt[rep] = digits[i0 + rep * PREP_NT];
+    __shared__ uint32_t stage_idx[PART_PTS];
+    __shared__ uint8_t stage_loc[PART_PTS];
+    __shared__ uint8_t stage_cell[PART_PTS];
+    const uint32_t t = threadIdx.x, w = blockIdx.y;
+    const uint32_t i0 = blockIdx.x * PART_PTS + EPT * t;   // this thread's 8 consecutive points
+    uint4 dv = make_uint4(0u, 0u, 0u, 0u);
+    if (i0 < n_pad) dv = *reinterpret_cast<const uint4 *>(digits + (size_t)w * n_pad + i0);   // n_pad is a multiple of 4096
+    // span starts of this window's cells
+    uint32_t cb, cell_n = 0;
     {
-        // Every workgroup scans the <= 2048 cell totals of the prepare kernel for itself (8 KB of loads) instead of waiting for a
-        // one-workgroup scan kernel between the two: one dependent launch less on the lane's stream.  Workgroup 0 publishes the result
-        // for the cell sort; the counters are zeroed for the next run by msm_segcount_kernel (after every partition workgroup has read
-        // them).  Cell spans start on 16-entry boundaries so the cell sort can fetch 16 entries per load.
-        const uint32_t ncells = W * G;
+        const uint32_t ncells = W * G, first = w * G;
         const uint32_t v0 = 2 * t < ncells ? B.cell_total[2 * t] : 0u, v1 = 2 * t + 1 < ncells ? B.cell_total[2 * t + 1] : 0u;
-        const uint32_t p0 = (v0 + 15u) & ~15u, p1 = (v1 + 15u) & ~15u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<PREP_NT>(p0 + p1, wave_tot, &total);
-        cbase[2 * t] = ex;
-        cbase[2 * t + 1] = ex + p0;
-        if (blockIdx.x == 0) {
-            if (2 * t < ncells) {
-                B.cell_base[2 * t] = ex;
-                B.cell_cnt[2 * t] = v0;
-            }
-            if (2 * t + 1 < ncells) {
-                B.cell_base[2 * t + 1] = ex + p0;
-                B.cell_cnt[2 * t + 1] = v1;
-            }
+        const uint32_t before = (2 * t < first ? ((v0 + 15u) & ~15u) : 0u) + (2 * t + 1 < first ? ((v1 + 15u) & ~15u) : 0u);
+        uint32_t base_w, win_tot;
+        (void)block_exclusive_scan<PREP_NT>(before, wave_tot, &base_w);          // padded entries of all earlier windows
+        if (t < G) cell_n = B.cell_total[first + t];
+        const uint32_t ex = block_exclusive_scan<PREP_NT>(t < G ? ((cell_n + 15u) & ~15u) : 0u, wave_tot, &win_tot);
+        cb = base_w + ex;
+        if (blockIdx.x == 0 && t < G) {
+            B.cell_base[first + t] = cb;
+            B.cell_cnt[first + t] = cell_n;
         }
-        __syncthreads();
     }
-    for (uint32_t w = 0; w < W; w++) {
-        if (t < 128) hist[t] = 0;
-        __syncthreads();
-        uint32_t rk[PREP_PPT], jj[PREP_PPT];
-        int dd[PREP_PPT];
+    if (t < 128) hist[t] = 0;
+    __syncthreads();
+    const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+    uint32_t rk[EPT], jj[EPT];
+    int dd[EPT];
 #pragma unroll
-        for (int rep = 0; rep < PREP_PPT; rep++) {
-            dd[rep] = nxt[rep];
-            if (w + 1 < W) nxt[rep] = digits[(size_t)(w + 1) * n_pad + i0 + rep * PREP_NT];  // in flight during this window's ranking
-            jj[rep] = (uint32_t)(dd[rep] < 0 ? -dd[rep] : dd[rep]) - 1u;
-            rk[rep] = dd[rep] != 0 ? atomicAdd(&hist[jj[rep] >> SEG_LOG], 1u) : 0u;
-        }
-        __syncthreads();
-        const uint32_t h = t < 128 ? hist[t] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan<PREP_NT>(h, wave_tot, &total);
-        if (t < 128) {
-            hist[t] = ex;
-            gpos[t] = (h && t < G) ? cbase[w * G + t] + atomicAdd(&B.cell_cursor[w * G + t], h) : 0u;
-        }
-        __syncthreads();
+    for (int k = 0; k < EPT; k++) {
+        dd[k] = (int)(int16_t)(dw[k >> 1] >> (16 * (k & 1)));
+        jj[k] = (uint32_t)(dd[k] < 0 ? -dd[k] : dd[k]) - 1u;
+        rk[k] = dd[k] != 0 ? atomicAdd(&hist[jj[k] >> SEG_LOG], 1u) : 0u;
+    }
+    __syncthreads();
+    const uint32_t h = t < 128 ? hist[t] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<PREP_NT>(h, wave_tot, &total);
+    if (t < 128) {
+        hist[t] = ex;
+        gpos[t] = (h && t < G) ? cb + atomicAdd(&B.cell_cursor[w * G + t], h) : 0u;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int rep = 0; rep < PREP_PPT; rep++) {
-            if (dd[rep] != 0) {
-                const uint32_t cellg = jj[rep] >> SEG_LOG;
-                const uint32_t p = hist[cellg] + rk[rep];
-                stage_idx[p] = (i0 + rep * PREP_NT) | (dd[rep] < 0 ? 0x80000000u : 0u);
-                stage_loc[p] = (uint8_t)(jj[rep] & (SEG_BUCKETS - 1));
-                stage_cell[p] = (uint8_t)cellg;
-            }
+    for (int k = 0; k < EPT; k++) {
+        if (dd[k] != 0) {
+            const uint32_t cellg = jj[k] >> SEG_LOG;
+            const uint32_t p = hist[cellg] + rk[k];
+            stage_idx[p] = (i0 + k) | (dd[k] < 0 ? 0x80000000u : 0u);
+            stage_loc[p] = (uint8_t)(jj[k] & (SEG_BUCKETS - 1));
+            stage_cell[p] = (uint8_t)cellg;
         }
-        __syncthreads();
-        for (uint32_t p = t; p < total; p += PREP_NT) {
-            const uint32_t cellg = stage_cell[p];
-            const uint32_t dst = gpos[cellg] + (p - hist[cellg]);
-            B.e_idx[dst] = stage_idx[p];
-            B.e_loc[dst] = stage_loc[p];
-        }
-        __syncthreads();
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < total; p += PREP_NT) {
+        const uint32_t cellg = stage_cell[p];
+        const uint32_t dst = gpos[cellg] + (p - hist[cellg]);
+        B.e_idx[dst] = stage_idx[p];
+        B.e_loc[dst] = stage_loc[p];
     }
 }
 
@@ -1003,8 +995,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         SortBufs B = sort_bufs(L);
         B.heavy_th = std::max<uint32_t>(32, 8 * (n_pad / nb));
         const uint32_t nbuckets_all = W * nb;
-        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B, n_pad, W,
-                           G);   // scans the cell totals itself
+        hipLaunchKernelGGL((msm_partition_kernel<0>), dim3((n_pad + PART_PTS - 1) / PART_PTS, W), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B,
+                           n_pad, W, G);   // scans the cell totals itself
         hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(G, W), dim3(CS_NT), 0, st, B, nb);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B, nb);
