@@ -30,7 +30,7 @@ plan.set_profiling(True)
 def run(k):
     pend, res, stage = [], None, np.zeros(4)
     for i in range(k):
-        if len(pend) == 3:
+        if len(pend) == plan.max_in_flight():
             res = plan.collect_limbs(pend.pop(0))
             stage += plan.stage_ms()
         pend.append(plan.submit(S.data_ptr(), P.data_ptr(), n, st))
