@@ -141,6 +141,8 @@ struct SortBufs {
     uint32_t heavy_th;
     uint32_t heavy_cap;     // capacity of heavy_tasks / heavy_buckets (entries)
     uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
+    uint32_t *big_ctr;      // [1] cells too large for msm_cellsort_kernel (zeroed by the scan kernel)
+    uint32_t *big_cells;    // [cells] their ids: the work list of msm_segcount_kernel / msm_segscatter_kernel
     uint2 *heavy_tasks;     // [heavy_cap] (bucket id, segment index)
     uint4 *heavy_buckets;   // [heavy_cap] (bucket id, first task, segments, -)
     // Device-side error counter of the lane (never reset: the host compares it with the value it saw last).  Bumped when an
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(SortBufs B, uint32_t nce
     B.size_hist[bin] = 0;
     B.size_cursor[bin] = 0;
     if (t < 2) B.heavy_ctr[t] = 0;
+    if (t == 2) *B.big_ctr = 0;
 }
 
 // Coarse radix pass, grid = (n_pad / 8192, W): one workgroup takes 8192 consecutive digits of ONE window (16 KB, read with 16-byte
@@ -348,7 +351,10 @@ __global__ __launch_bounds__(CS_NT) void msm_cellsort_kernel(SortBufs B, uint32_
         B.cell_total[cellid] = 0;
         B.cell_cursor[cellid] = 0;
     }
-    if (seg_n > CS_MAX) return;
+    if (seg_n > CS_MAX) {   // left to the multi-workgroup pair, which walks this list
+        if (t == 0) B.big_cells[atomicAdd(B.big_ctr, 1u)] = cellid;
+        return;
+    }
     const uint32_t base = g * SEG_BUCKETS;
     const uint32_t nloc = min((uint32_t)SEG_BUCKETS, nb - base);
     const size_t flat0 = (size_t)w * nb + base;
@@ -402,32 +408,38 @@ __global__ __launch_bounds__(CS_NT) void msm_cellsort_kernel(SortBufs B, uint32_
         *reinterpret_cast<uint4 *>(sorted + e0) = make_uint4(img[e0], img[e0 + 1], img[e0 + 2], img[e0 + 3]);
 }
 
-// Cell sort, large cells, grid = (SEG_Z, G, W): up to SEG_Z workgroups share a cell and take its 4096-entry chunks
+// Cell sort, large cells, grid = (SEG_Z, SEG_LIST): the cells msm_cellsort_kernel registered as too large (normally none: both
+// kernels then return at once) are taken from its list; up to SEG_Z workgroups share a cell and take its 4096-entry chunks
 // round-robin, so a cell swollen by skewed scalars (a hot digit) is still sorted by several CUs.
 // Kernel 1 counts: zcount[cell][z][b] = entries of bucket b in the chunks of workgroup z.
+constexpr int SEG_LIST = 64;     // grid.y of the pair: list entries are taken round-robin
 template <int DUMMY>
 __global__ __launch_bounds__(SEG_NT) void msm_segcount_kernel(SortBufs B) {
     __shared__ uint32_t hist[SEG_BUCKETS];
-    const uint32_t t = threadIdx.x, z = blockIdx.x, g = blockIdx.y, w = blockIdx.z, G = gridDim.y;
-    const uint32_t cellid = w * G + g;
-    const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
-    const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
-    if (seg_n <= CS_MAX || z >= nchunks) return;   // small cells were sorted by msm_cellsort_kernel
-    const uint8_t *__restrict__ loc = B.e_loc + seg0;
-    hist[t] = 0;
-    __syncthreads();
-    for (uint32_t ch = z; ch < nchunks; ch += SEG_Z) {
-        const uint32_t c0 = ch * SEG_CHUNK, cn = min((uint32_t)SEG_CHUNK, seg_n - c0);
-        if (SEG_EPT * t < cn) {
-            const uint4 lv = *reinterpret_cast<const uint4 *>(loc + c0 + SEG_EPT * t);  // thread t owns entries 16t .. 16t+15
-            const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
+    const uint32_t t = threadIdx.x, z = blockIdx.x, nbig = *B.big_ctr;
+    for (uint32_t ci = blockIdx.y; ci < nbig; ci += gridDim.y) {
+        const uint32_t cellid = B.big_cells[ci];
+        const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
+        const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
+        if (z < nchunks) {
+            const uint8_t *__restrict__ loc = B.e_loc + seg0;
+            hist[t] = 0;
+            __syncthreads();
+            for (uint32_t ch = z; ch < nchunks; ch += SEG_Z) {
+                const uint32_t c0 = ch * SEG_CHUNK, cn = min((uint32_t)SEG_CHUNK, seg_n - c0);
+                if (SEG_EPT * t < cn) {
+                    const uint4 lv = *reinterpret_cast<const uint4 *>(loc + c0 + SEG_EPT * t);  // thread t owns entries 16t .. 16t+15
+                    const uint32_t lw[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
-            for (int k = 0; k < SEG_EPT; k++)
-                if (SEG_EPT * t + k < cn) atomicAdd(&hist[(lw[k >> 2] >> (8 * (k & 3))) & 0xffu], 1u);
+                    for (int k = 0; k < SEG_EPT; k++)
+                        if (SEG_EPT * t + k < cn) atomicAdd(&hist[(lw[k >> 2] >> (8 * (k & 3))) & 0xffu], 1u);
+                }
+            }
+            __syncthreads();
+            B.zcount[((size_t)cellid * SEG_Z + z) * SEG_BUCKETS + t] = hist[t];
         }
+        __syncthreads();
     }
-    __syncthreads();
-    B.zcount[((size_t)cellid * SEG_Z + z) * SEG_BUCKETS + t] = hist[t];
 }
 
 // Kernel 2 scatters: bucket starts from the summed counts (workgroup 0 of the cell also publishes
@@ -435,22 +447,23 @@ __global__ __launch_bounds__(SEG_NT) void msm_segcount_kernel(SortBufs B) {
 // (LDS-atomic ranks, block scan, staging buffer) and writes them out as per-bucket runs behind the
 // runs of the workgroups before it.  The order inside a bucket is irrelevant to the sum.
 template <int DUMMY>
-__global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint32_t nb) {
+__global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint32_t nb, uint32_t G) {
     __shared__ uint32_t cur[SEG_BUCKETS];      // running global write position of every bucket
     __shared__ uint32_t ch_hist[SEG_BUCKETS];  // per-chunk: entries per bucket, then exclusive offsets
     __shared__ uint32_t hist[SIZE_BINS];
     __shared__ uint32_t wave_tot[SEG_NT / 64 + 1];
     __shared__ uint32_t stage_idx[SEG_CHUNK];
     __shared__ uint8_t stage_loc[SEG_CHUNK];
-    const uint32_t t = threadIdx.x, z = blockIdx.x, g = blockIdx.y, w = blockIdx.z, G = gridDim.y;
-    const uint32_t cellid = w * G + g;
+    const uint32_t t = threadIdx.x, z = blockIdx.x, nbig = *B.big_ctr;
+    for (uint32_t ci = blockIdx.y; ci < nbig; ci += gridDim.y) {
+    const uint32_t cellid = B.big_cells[ci], g = cellid % G, w = cellid / G;
     const uint32_t base = g * SEG_BUCKETS;
     const uint32_t nloc = min((uint32_t)SEG_BUCKETS, nb - base);
     const size_t flat0 = (size_t)w * nb + base;
     const uint32_t seg0 = B.cell_base[cellid], seg_n = B.cell_cnt[cellid];
     const uint32_t nchunks = (seg_n + SEG_CHUNK - 1) / SEG_CHUNK;
     const uint32_t active = min((uint32_t)SEG_Z, nchunks);
-    if (seg_n <= CS_MAX || z >= active) return;   // small (and empty) cells were sorted and published by msm_cellsort_kernel
+    if (z < active) {   // (uniform over the workgroup)
     const uint8_t *__restrict__ loc = B.e_loc + seg0;
     const uint32_t *__restrict__ idx = B.e_idx + seg0;
     uint32_t *__restrict__ sorted = B.sorted;
@@ -524,6 +537,9 @@ __global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint
         cur[t] += hc;
         __syncthreads();
     }
+    }   // z < active
+    __syncthreads();
+    }   // list of large cells
 }
 
 // grid covers the flattened bucket array, 2 buckets per thread: ranks the buckets by list length
@@ -921,8 +937,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.e_loc.alloc(dig / 2 + span_slack);
         L.cells.alloc(4 * MAX_CELLS * sizeof(uint32_t));  // cell_total | cell_base | cell_cnt | cell_cursor
         ZK_HIP(hipMemset(L.cells.p, 0, 4 * MAX_CELLS * sizeof(uint32_t)));
-        L.size_bins.alloc((3 * SIZE_BINS + 2) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2]
-        ZK_HIP(hipMemset(L.size_bins.p, 0, (3 * SIZE_BINS + 2) * sizeof(uint32_t)));
+        L.size_bins.alloc((3 * SIZE_BINS + 4 + MAX_CELLS) * sizeof(uint32_t));  // size_hist | size_base | size_cursor | heavy_ctr[2] | big_ctr, pad | big_cells
+        ZK_HIP(hipMemset(L.size_bins.p, 0, (3 * SIZE_BINS + 4 + MAX_CELLS) * sizeof(uint32_t)));
         L.zcount.alloc((size_t)MAX_CELLS * SEG_Z * SEG_BUCKETS * sizeof(uint32_t));
         L.heavy_tasks.alloc((size_t)heavy_cap * sizeof(uint2));
         L.heavy_buckets.alloc((size_t)heavy_cap * sizeof(uint4));
@@ -983,6 +999,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         B.heavy_th = 32;
         B.heavy_cap = heavy_cap;
         B.heavy_ctr = B.size_hist + 3 * SIZE_BINS;
+        B.big_ctr = B.heavy_ctr + 2;
+        B.big_cells = B.heavy_ctr + 4;
         B.heavy_tasks = L.heavy_tasks.template as<uint2>();
         B.heavy_buckets = L.heavy_buckets.template as<uint4>();
         B.err = err_dev(L);
@@ -998,8 +1016,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_partition_kernel<0>), dim3((n_pad + PART_PTS - 1) / PART_PTS, W), dim3(PREP_NT), 0, st, L.digits.template as<int16_t>(), B,
                            n_pad, W, G);   // scans the cell totals itself
         hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(G, W), dim3(CS_NT), 0, st, B, nb);
-        hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B);
-        hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, G, W), dim3(SEG_NT), 0, st, B, nb);
+        hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, st, B);   // cells beyond CS_MAX entries only
+        hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, st, B, nb, G);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, st, B, G * W);
         hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((nbuckets_all + 2047) / 2048), dim3(1024), 0, st, B, nbuckets_all);
         mark(L, 2);
@@ -1086,8 +1104,8 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
                            L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total);
         hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(FIX_G, 1), dim3(CS_NT), 0, ls, B, FIX_NB);
-        hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B);
-        hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, FIX_G, 1), dim3(SEG_NT), 0, ls, B, FIX_NB);
+        hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, ls, B);
+        hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, ls, B, FIX_NB, (uint32_t)FIX_G);
         hipLaunchKernelGGL((msm_scan_kernel<true>), dim3(1), dim3(1024), 0, ls, B, FIX_G);
         hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((FIX_NB + 2047) / 2048), dim3(1024), 0, ls, B, FIX_NB);
         mark(L, 2);
