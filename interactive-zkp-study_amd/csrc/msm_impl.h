@@ -412,7 +412,7 @@ __global__ __launch_bounds__(CS_NT) void msm_cellsort_kernel(SortBufs B, uint32_
 // kernels then return at once) are taken from its list; up to SEG_Z workgroups share a cell and take its 4096-entry chunks
 // round-robin, so a cell swollen by skewed scalars (a hot digit) is still sorted by several CUs.
 // Kernel 1 counts: zcount[cell][z][b] = entries of bucket b in the chunks of workgroup z.
-constexpr int SEG_LIST = 64;     // grid.y of the pair: list entries are taken round-robin
+constexpr int SEG_LIST = 256;    // grid.y of the pair: list entries are taken round-robin
 template <int DUMMY>
 __global__ __launch_bounds__(SEG_NT) void msm_segcount_kernel(SortBufs B) {
     __shared__ uint32_t hist[SEG_BUCKETS];
