@@ -6,11 +6,12 @@
 //
 //   prepare      one thread per point: canonical affine -> Montgomery affine packed to one 64-byte line (resident
 //                for all windows), scalar -> W signed c-bit digits (int16, window-major), per-cell histogram.
-//   bucket sort  scan -> partition (by cell = 256 buckets of one window, LDS-staged) -> segcount / segscatter
-//                (per-cell LDS counting sort, up to 8 workgroups per cell) -> rank (buckets by list length).
+//   bucket sort  partition (by cell = 256 buckets of one window, LDS-staged; scans the cell totals itself) -> cell sort (one
+//                workgroup per cell, single pass through LDS; cells beyond 10240 entries go to the multi-workgroup count /
+//                scatter pair) -> scan + rank (buckets by list length).
 //   accumulate   one thread per bucket, one wavefront per workgroup, lists of equal length side by side; XYZZ mixed
-//                additions (8M+2S) with a two-deep load pipeline.  Lists longer than heavy_th go to the heavy-bucket
-//                kernels (wavefront tasks of 64 segments, __shfl trees).
+//                additions (8M+2S).  Lists longer than heavy_th go to the heavy-bucket kernel (wavefront tasks of 64
+//                segments, __shfl trees, per-bucket last-arriver combine).
 //   reduce       sum_j (j+1)*B_j per window without any serial running sum, in place: pair levels plus plain-sum trees
 //                over the odd entries of every level (sum_j j*B_j = sum_l 2^l * O_l).
 //   fold (host)  the W*c window/level sums are read back and combined by one 254-doubling Horner pass on the host
@@ -97,7 +98,9 @@ template <int NT> __device__ __forceinline__ uint32_t block_exclusive_scan(uint3
 //   partition  coarse radix pass: every (window, point) entry is written to its cell's segment
 //              (index | sign << 31 in e_idx, bucket-in-cell byte in e_loc); a workgroup reserves one
 //              contiguous span per cell, so writes are short runs, never single scattered words.
-//   segcount / segscatter
+//   cellsort   one workgroup sorts a whole cell (<= CS_MAX entries) in one pass: entries in registers, LDS-atomic ranks,
+//              scan of the 256 counters (-> counts[], bucket_off[]), LDS image of the sorted cell, coalesced write.
+//   segcount / segscatter  (cells beyond CS_MAX entries only, from the list msm_cellsort_kernel writes)
 //              up to SEG_Z workgroups per cell take its 4096-entry chunks round-robin: count the 256 buckets
 //              (-> counts[], bucket_off[]), then sort every chunk entirely in LDS (LDS-atomic ranks, block
 //              scan, staging buffer) and write it out as per-bucket runs -- coalesced 16-byte reads,
