@@ -28,7 +28,7 @@ template <class F> struct Xyzz {
 
 // Value bounds (multiples of the modulus m) maintained by every routine below; they are what the
 // K arguments of fe_sub<K> / fe_neg<K> encode (field.h contracts; mul outputs are < 2m):
-//   affine coordinates < 2m;   XYZZ:  X < 8m,  Y < 4m,  ZZ < 2m,  ZZZ < 2m.
+//   affine coordinates < 2m;   XYZZ:  X < 8m,  Y < 4m,  ZZ < 2m,  ZZZ < 2m   (G2: X < 4p per component, everything else < 2p).
 template <class F> ZK_HD Affine<F> affine_neg(const Affine<F> &p) { return Affine<F>{p.x, fe_neg<2>(p.y)}; }
 template <class F> ZK_HD Xyzz<F> xyzz_neg(const Xyzz<F> &p) { return Xyzz<F>{p.x, fe_neg<4>(p.y), p.zz, p.zzz}; }
 
@@ -88,6 +88,40 @@ template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) 
     F y3 = fe_mulsub<4>(r, fe_sub_once<8>(qq, x3), acc.y, ppp);      // 6.1*11 + 5*2 < 169;  < 2m
     acc.x = x3;
     acc.y = y3;
+    acc.zz = fe_mul(acc.zz, pp);
+    acc.zzz = fe_mul(acc.zzz, ppp);
+}
+
+// The same for G2, with the lazier F_p^2 forms of field.h (the accumulate kernel is issue-bound, and every conditional subtraction
+// and carry chain that F_p^2's "everything below 2p" convention costs is an instruction it executes 13-16 million times per MSM):
+// bounds per component  X < 4p,  Y < 2p,  ZZ, ZZZ < 2p;  P = U2 - X1 < 6.06p and R = S2 - Y1 < 4.06p come straight out of their
+// products (fp2_mul_minus_lazy), their squares take them as they are (fp2_sqr_lazy), X3 needs ONE conditional subtraction (of 4p)
+// instead of three, Q - X3 is only normalised.  q.y may be a negated table entry (fe_neg_once<2> of F_p^2: normalised, <= 2p).
+ZK_HD void xyzz_add_affine(Xyzz<Fp2> &acc, const Affine<Fp2> &q) {
+    if (q.is_inf()) return;
+    if (acc.is_inf()) {
+        acc = Xyzz<Fp2>{q.x, q.y, Fp2::one(), Fp2::one()};
+        return;
+    }
+    const Fp2 p = fp2_mul_minus_lazy<4>(q.x, acc.zz, acc.x);    // < 6.06p
+    const Fp2 r = fp2_mul_minus_lazy<2>(q.y, acc.zzz, acc.y);   // < 4.06p
+    if (p.is_zero()) {
+        if (r.is_zero())
+            acc = xyzz_dbl_affine(q);
+        else
+            acc = Xyzz<Fp2>::inf();
+        return;
+    }
+    const Fp2 pp = fp2_sqr_lazy<7>(p);       // 12.12 * 13.06 < 169
+    const Fp2 ppp = fe_mul(p, pp);           // 6.06 * (2 + 3)
+    const Fp2 qq = fe_mul(acc.x, pp);        // 4 * (2 + 3)
+    const Fp2 rr = fp2_sqr_lazy<5>(r);       // 8.12 * 9.06
+    Fp2 x3{fe_sub2<6>(rr.c0, ppp.c0, qq.c0), fe_sub2<6>(rr.c1, ppp.c1, qq.c1)};   // r^2 - ppp - 2 qq + 6p < 8p
+    fe_cond_sub<4>(x3.c0);                   // < 4p
+    fe_cond_sub<4>(x3.c1);
+    const Fp2 d{fe_sub_k<4>(qq.c0, x3.c0), fe_sub_k<4>(qq.c1, x3.c1)};            // < 6p
+    acc.y = fp2_mulsub_lazy<6>(r, d, acc.y, ppp);                                  // 4.06 * (6 + 7) + 2 * 2 + 3 * 2 < 169;  < 2p
+    acc.x = x3;
     acc.zz = fe_mul(acc.zz, pp);
     acc.zzz = fe_mul(acc.zzz, ppp);
 }

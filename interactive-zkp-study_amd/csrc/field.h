@@ -325,6 +325,15 @@ template <class Tag> ZK_HD Fe<Tag> fe_dbl(const Fe<Tag> &a) {
     ZK_DBG(r.vb = 2 * a.vb;)
     return r;
 }
+// 2a with no carry propagation (limbs < 2 * 2^29 for a normalised a): only as a direct operand of fe_mul
+template <class Tag> ZK_HD Fe<Tag> fe_dbl_lazy(const Fe<Tag> &a) {
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] << 1;
+    ZK_DBG_ASSERT(a.lmax <= 2, "fe_dbl_lazy: limb overflow");
+    ZK_DBG(r.vb = 2 * a.vb; r.lmax = 2 * a.lmax;)
+    return r;
+}
 template <class Tag> ZK_HD Fe<Tag> fe_triple(const Fe<Tag> &a) {
     Fe<Tag> r;
 #pragma unroll
@@ -457,6 +466,56 @@ template <int K, class Tag> ZK_HD Fe<Tag> fe_mulsub(const Fe<Tag> &a, const Fe<T
     const Fe<Tag> *const x[2] = {&a, &nc};
     const Fe<Tag> *const y[2] = {&b, &d};
     return fe_dot<2>(x, y);
+}
+
+// fe_dot with an addend riding in the UPPER half of the double-width sum (limb j lands in column NL + j, i.e. times R), as in
+// fe_mul_minus: sum_t a[t]*b[t] / R + add out of the one reduction.  add: limbs < 2^30, not necessarily normalised (typically
+// fe_neg_lazy<K>(c): the F_p^2 form of "a*b - c", both components of which are two-product sums).  Result normalised,
+// value < sum va*vb / 169 + 1 + value(add).
+template <int N, class Tag> ZK_HD Fe<Tag> fe_dot_add(const Fe<Tag> *const (&a)[N], const Fe<Tag> *const (&b)[N], const Fe<Tag> &add) {
+    typedef FieldConst<Tag> C;
+    static_assert(N * 9 + 11 < 64, "fe_dot_add: column accumulator would overflow");
+    uint32_t q[NL];
+    Fe<Tag> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+#pragma unroll
+            for (int i = 0; i <= k; i++) acc += (uint64_t)a[t]->l[i] * b[t]->l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        q[k] = ((uint32_t)acc * C::inv) & LMASK;
+        acc += (uint64_t)q[k] * C::mod(0);
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int t = 0; t < N; t++)
+#pragma unroll
+            for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)a[t]->l[i] * b[t]->l[k - i];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)q[i] * C::mod(k - i);
+        acc += add.l[k - NL];
+        r.l[k - NL] = (uint32_t)acc & LMASK;
+        acc >>= LB;
+    }
+    r.l[NL - 1] = (uint32_t)acc + add.l[NL - 1];
+#ifdef ZK_FIELD_DEBUG
+    double vsum = 0, lsum = 0;
+    for (int t = 0; t < N; t++) {
+        vsum += a[t]->vb * b[t]->vb;
+        lsum += 9.0 * a[t]->lmax * b[t]->lmax;
+    }
+    ZK_DBG_ASSERT(lsum + 9.0 + 1.0 + 1.0 < 64.0, "fe_dot_add: column accumulator may overflow");
+    ZK_DBG_ASSERT(vsum < 169.0, "fe_dot_add: sum of value bounds >= 169");
+    ZK_DBG_ASSERT(add.lmax <= 2 && add.vb <= 16, "fe_dot_add: addend out of range");
+    r.vb = vsum / 169.0 + 1.0 + add.vb;
+    r.lmax = 1;
+#endif
+    return r;
 }
 
 // Montgomery square: 45 distinct products instead of 81.
@@ -649,10 +708,37 @@ template <int K> ZK_HD Fp2 fe_mulsub(const Fp2 &a, const Fp2 &b, const Fp2 &c, c
 // (c0+c1 i)^2 = (c0+c1)(c0-c1) + 2 c0 c1 i : 2 base-field products.
 ZK_HD Fp2 fe_sqr(const Fp2 &a) {
     const Fp t = fe_mul(a.c0, a.c1);
-    const Fp u = fe_mul(fe_add_lazy(a.c0, a.c1), fe_sub_k<2>(a.c0, a.c1));
+    const Fp u = fe_mul(fe_add_lazy(a.c0, a.c1), fe_sub_k<4>(a.c0, a.c1));   // components up to 4p (X of a G2 accumulator): 8 * 8 < 169
     Fp2 r{u, fe_dbl(t)};
     fe_wreduce<4>(r.c1);
     return r;
+}
+// ---- lazier forms for the G2 mixed addition (curve.h): components may exceed 2p where the comment says so; everything is normalised.
+// a*b - c with c riding in the upper columns of both components' sums (no separate subtraction, carry chain or conditional
+// subtraction): a, b < 2p (b.c1 normalised), c <= K*p normalised;  components < 10/169 + K + 2 (in units of p).
+template <int K> ZK_HD Fp2 fp2_mul_minus_lazy(const Fp2 &a, const Fp2 &b, const Fp2 &c) {
+    const Fp nb1 = fe_neg_lazy<2>(b.c1);
+    const Fp n0 = fe_neg_lazy<K>(c.c0), n1 = fe_neg_lazy<K>(c.c1);   // (K+1)p - c, limbs < 2^30
+    const Fp *const x[2] = {&a.c0, &a.c1};
+    const Fp *const y0[2] = {&b.c0, &nb1};
+    const Fp *const y1[2] = {&b.c1, &b.c0};
+    return Fp2{fe_dot_add<2>(x, y0, n0), fe_dot_add<2>(x, y1, n1)};
+}
+// a^2 for components <= K*p (K <= 7: (2K)(2K + 1) < 169 needs K <= 6.2, the callers' bounds are 4.06 and 6.06): the doubling of
+// 2 c0 c1 is a limb shift of one operand, nothing is conditionally subtracted;  components < 2p.
+template <int K> ZK_HD Fp2 fp2_sqr_lazy(const Fp2 &a) {
+    const Fp u = fe_mul(fe_add_lazy(a.c0, a.c1), fe_sub_k<K>(a.c0, a.c1));
+    const Fp t2 = fe_mul(fe_dbl_lazy(a.c0), a.c1);
+    return Fp2{u, t2};
+}
+// a*b - c*d for a <= ~4p, b <= KB*p, c < 2p, d < 2p (all normalised), two reductions;  components < 2p.
+template <int KB> ZK_HD Fp2 fp2_mulsub_lazy(const Fp2 &a, const Fp2 &b, const Fp2 &c, const Fp2 &d) {
+    const Fp nb1 = fe_neg_lazy<KB>(b.c1), nc0 = fe_neg_k<2>(c.c0), nc1 = fe_neg_lazy<2>(c.c1);
+    const Fp *const x0[4] = {&a.c0, &a.c1, &nc0, &c.c1};
+    const Fp *const y0[4] = {&b.c0, &nb1, &d.c0, &d.c1};
+    const Fp *const x1[4] = {&a.c0, &a.c1, &nc0, &nc1};
+    const Fp *const y1[4] = {&b.c1, &b.c0, &d.c1, &d.c0};
+    return Fp2{fe_dot<4>(x0, y0), fe_dot<4>(x1, y1)};
 }
 ZK_HD Fp2 fe_inv(const Fp2 &a) {
     const Fp d = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));

@@ -189,6 +189,9 @@ class ScaleProver:
         # array with the scalars (r*u_B | 0 0 r | w | h) behind each other -- the same bucket additions, one sort and one bucket
         # reduction instead of three.  h (m coefficients, the last one zero) is computed in place at the tail of that buffer.
         self.sc_c = new(self.n_c + 1) if self.bound else None
+        # the per-proof constant-term scalars (they depend on r and s) go up in ONE asynchronous copy from a pinned buffer
+        self.h_consts = torch.empty((8, 4), dtype=torch.int64).pin_memory()
+        self.d_consts = new(8)
         self.zinv = pow((pow(COSET_SHIFT, self.m, R) - 1) % R, -1, R)  # 1 / Z_H on the coset k*H
 
     def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
@@ -208,12 +211,18 @@ class ScaleProver:
         if self.bound:
             h = self.sc_c[self.off15:self.off15 + m]           # the H coefficients land where the merged MSM reads them
         ua, ub = self.ext_a[:m], self.ext_b1[:m]
-        ua.copy_(d_a)
-        ub.copy_(d_b)
-        # constant-term scalars behind the coefficient vectors (see ScaleCRS): [1, r, 0] / [0, 0, 1] / [1, s]
-        self.ext_a[m:] = _dev(_lib.ints_to_limbs([1, r, 0]))
-        self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
-        self.ext_b2[m:] = _dev(_lib.ints_to_limbs([1, s]))
+        # constant-term scalars behind the coefficient vectors (see ScaleCRS; bases alpha | delta | beta resp. beta | delta):
+        #   A: [1, r, 0]    B1: [0, 0, 1]    B2: [1, s]    merged proof_C query (bound CRS): [s, r*s, r]
+        self.h_consts.numpy().view(np.uint64)[:] = _lib.ints_to_limbs([1, r, 0, 1, s, s, r * s % R, r])
+        self.d_consts.copy_(self.h_consts, non_blocking=True)
+        if ua.data_ptr() != d_a.data_ptr():
+            ua.copy_(d_a)
+        if ub.data_ptr() != d_b.data_ptr():
+            ub.copy_(d_b)
+        self.ext_a[m:] = self.d_consts[0:3]
+        self.ext_b2[m:] = self.d_consts[3:5]
+        if not self.bound:
+            self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
         # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.): 3 inverse NTTs
         for d in (ua, ub, d_c):
             self.ntt.run(d.data_ptr(), True, None, st)
@@ -233,16 +242,18 @@ class ScaleProver:
         t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
         t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
         if self.bound:
+            # proving.py:47-75 with the +-r*s*delta terms cancelled:  proof_C = s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H, and
+            # s*A = s*alpha*G1 + MSM(s*u_A, sigma1_2) + r*s*delta*G1 is a combination of the same bases: the whole of proof_C is ONE
+            # MSM with the scalars (s*u_A + r*u_B | s, r*s, r | w | h) -- no two-point combination (a pipeline of its own and a host
+            # round trip) behind the last bucket reduction, and proof_C does not wait for proof_A.
             sc = self.sc_c
-            FrVec.lincomb(sc.data_ptr(), [ub.data_ptr()], [r], m, stream=st)             # r * u_B
-            sc[m:m + 3] = _dev(_lib.ints_to_limbs([0, 0, r]))                            # r * beta
+            FrVec.lincomb(sc.data_ptr(), [ua.data_ptr(), ub.data_ptr()], [s, r], m, stream=st)   # s * u_A + r * u_B
+            sc[m:m + 3] = self.d_consts[5:8]
             sc[self.off14:self.off15].copy_(d_w)                                         # placeholders at public wires are infinity
-            t_c = self.g1.submit_bound(sc.data_ptr(), 0, self.n_c, st)                   # r*(beta + B(x)) + L + H
-            proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                      # proving.py:23-33
-            msm_c = self._pt(self.g1, self.g1.collect_limbs(t_c))
+            t_c = self.g1.submit_bound(sc.data_ptr(), 0, self.n_c, st)
             proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                     # proving.py:35-45
-            # proving.py:47-75 with the +-r*s*delta terms cancelled:  s*A + [r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H]
-            proof_c = msm_g1([s, 1], [proof_a, msm_c])
+            proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                      # proving.py:23-33
+            proof_c = self._pt(self.g1, self.g1.collect_limbs(t_c))
             return proof_a, proof_b, proof_c, h
         t_b1 = self._msm(self.g1, self.ext_b1, crs.d_s12, 0, m + 3, st)                  # beta + B(x) in G1
         t_h = self._msm(self.g1, h, crs.d_s15, self.off15, m - 1, st)

@@ -151,4 +151,24 @@ void hm_g1_accumulate(const uint64_t *pts, uint32_t n, const uint8_t *negate, ui
     HFp x = fe_from_mont(a.x), y = fe_from_mont(a.y);
     memcpy(o, x.l, 32); memcpy(o + 4, y.l, 32);
 }
+// the same for G2 (its mixed addition has bounds of its own: curve.h), result through the device-side conversion
+void hm_g2_accumulate(const uint64_t *pts, uint32_t n, const uint8_t *negate, uint64_t *o) {
+    G2Xyzz acc = G2Xyzz::inf();
+    for (uint32_t i = 0; i < n; i++) {
+        G2Affine q = g2_load(pts + 16 * i);
+        if (negate && negate[i]) q.y = fe_neg_once<2>(q.y);
+        xyzz_add_affine(acc, q);
+    }
+    // what the bucket reduction does with such an accumulator: a full addition and a doubling take it as an operand
+    G2Xyzz twice = acc;
+    xyzz_add(twice, acc);
+    G2Xyzz dbl = xyzz_dbl(acc);
+    G2Affine a = xyzz_to_affine(acc), b = xyzz_to_affine(twice), c = xyzz_to_affine(dbl);
+    store4(o, fe_from_mont(a.x.c0)); store4(o + 4, fe_from_mont(a.x.c1));
+    store4(o + 8, fe_from_mont(a.y.c0)); store4(o + 12, fe_from_mont(a.y.c1));
+    store4(o + 16, fe_from_mont(b.x.c0)); store4(o + 20, fe_from_mont(b.x.c1));
+    store4(o + 24, fe_from_mont(b.y.c0)); store4(o + 28, fe_from_mont(b.y.c1));
+    store4(o + 32, fe_from_mont(c.x.c0)); store4(o + 36, fe_from_mont(c.x.c1));
+    store4(o + 40, fe_from_mont(c.y.c0)); store4(o + 44, fe_from_mont(c.y.c1));
+}
 }

@@ -152,6 +152,31 @@ def test_long_accumulation_chain_keeps_bounds(hm):
         assert co.g1_from_arr(O)[0] == co.g1_mul(o.G1, k % o.R)
 
 
+def test_long_g2_accumulation_chain_keeps_bounds(hm):
+    """200 mixed additions in one G2 accumulator (its mixed addition keeps X below 4p and lets P, R and Q - X3 run above 2p: curve.h),
+    with negations, a repeated point (doubling branch) and a cancelling pair; then the accumulator as an operand of a full addition
+    and of a doubling, as the bucket reduction uses it.  The ZK_FIELD_DEBUG build aborts on any bound the formulas overstep."""
+    rnd = random.Random(8)
+    n = 200
+    ks = [rnd.randrange(1, o.R) for _ in range(n)]
+    ks[10] = ks[9]
+    ks[21] = ks[20]
+    pts = [co.g2_mul(o.G2, k) for k in ks]
+    neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
+    neg[9] = neg[10] = 0
+    neg[21] = 1 - neg[20]
+    total = sum((-k if s else k) for k, s in zip(ks, neg)) % o.R
+    O = np.zeros(48, dtype=np.uint64)
+    hm.hm_g2_accumulate(P(co.g2_to_arr(pts)), ctypes.c_uint32(n), P(neg), P(O))
+    got = co.g2_from_arr(O)
+    assert got[0] == co.g2_mul(o.G2, total)
+    assert got[1] == got[2] == co.g2_mul(o.G2, 2 * total % o.R)
+    # negated entries on the paths that keep q.y: first addition into an empty accumulator, doubling; everything cancelling
+    for sel, negs, k in (([0], [1], -ks[0]), ([0, 0], [1, 1], -2 * ks[0]), ([1, 0, 0], [0, 1, 1], ks[1] - 2 * ks[0]), ([0, 0, 1, 1], [0, 1, 1, 0], 0)):
+        hm.hm_g2_accumulate(P(co.g2_to_arr([pts[i] for i in sel])), ctypes.c_uint32(len(sel)), P(np.array(negs, dtype=np.uint8)), P(O))
+        assert co.g2_from_arr(O)[0] == co.g2_mul(o.G2, k % o.R)
+
+
 def test_sanitizer_build_is_clean():
     """the CPU path under sanitizers.  tests/hostmath/sanitize_check links the device math compiled for
     the host, the product's host code (csrc/pairing.hip) and the C oracle with -fsanitize=address,undefined

@@ -11,9 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
 
 
-def run(log_m, reps):
+def run(log_m, reps, lib_path=""):
     import torch
     from zkhip import _lib
+    if lib_path:
+        _lib.LIB_PATH = lib_path   # another build of libzkhip.so, for same-session A/B runs
     from zkhip.field import G1, G2, ec_mul
     from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver, closed_form_scalars
     t0 = time.perf_counter()
@@ -48,5 +50,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--lib", default="")
     args = ap.parse_args()
-    print(json.dumps(run(args.log_m, args.reps)), flush=True)
+    print(json.dumps(run(args.log_m, args.reps, args.lib)), flush=True)

@@ -24,12 +24,15 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--n", type=int, default=0, help="points (default 2^log_n)")
     ap.add_argument("--bits", type=int, default=0, help="keep only the low BITS bits of every scalar (0 = uniform below r)")
+    ap.add_argument("--lib", default="", help="another build of libzkhip.so (same-session A/B runs; default: the in-tree library)")
     args = ap.parse_args()
     import time
 
     import torch
     from zkhip.synthetic import random_scalars
     from zkhip import _lib
+    if args.lib:
+        _lib.LIB_PATH = args.lib
     from zkhip.device import MsmPlan
 
     lib = _lib.load()
