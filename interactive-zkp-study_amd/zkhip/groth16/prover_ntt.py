@@ -237,19 +237,21 @@ class ScaleProver:
             self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
+        if self.bound:
+            # proving.py:47-75 with the +-r*s*delta terms cancelled:  proof_C = s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H, and
+            # s*A = s*alpha*G1 + MSM(s*u_A, sigma1_2) + r*s*delta*G1 is a combination of the same bases: the whole of proof_C is ONE
+            # MSM with the scalars (s*u_A + r*u_B | s, r*s, r | w | h) -- no two-point combination (a pipeline of its own and a host
+            # round trip) behind the last bucket reduction, and proof_C does not wait for proof_A.  Its scalars are put together
+            # BEFORE any MSM is submitted: a small kernel queued behind an accumulate grid waits for that whole grid.
+            sc = self.sc_c
+            FrVec.lincomb(sc.data_ptr(), [ua.data_ptr(), ub.data_ptr()], [s, r], m, stream=st)   # s * u_A + r * u_B
+            sc[m:m + 3] = self.d_consts[5:8]
+            sc[self.off14:self.off15].copy_(d_w)                                         # placeholders at public wires are infinity
         # The MSMs, each in its own workspace and stream (the G1 plan keeps three in flight).  The G2 one leads: its long,
         # latency-bound bucket reduction then runs beside the G1 accumulate kernels instead of alone.
         t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
         t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
         if self.bound:
-            # proving.py:47-75 with the +-r*s*delta terms cancelled:  proof_C = s*A + r*(beta*G1 + MSM(u_B, sigma1_2)) + L + H, and
-            # s*A = s*alpha*G1 + MSM(s*u_A, sigma1_2) + r*s*delta*G1 is a combination of the same bases: the whole of proof_C is ONE
-            # MSM with the scalars (s*u_A + r*u_B | s, r*s, r | w | h) -- no two-point combination (a pipeline of its own and a host
-            # round trip) behind the last bucket reduction, and proof_C does not wait for proof_A.
-            sc = self.sc_c
-            FrVec.lincomb(sc.data_ptr(), [ua.data_ptr(), ub.data_ptr()], [s, r], m, stream=st)   # s * u_A + r * u_B
-            sc[m:m + 3] = self.d_consts[5:8]
-            sc[self.off14:self.off15].copy_(d_w)                                         # placeholders at public wires are infinity
             t_c = self.g1.submit_bound(sc.data_ptr(), 0, self.n_c, st)
             proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                     # proving.py:35-45
             proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                      # proving.py:23-33
