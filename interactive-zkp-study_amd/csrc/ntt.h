@@ -37,6 +37,12 @@ struct NttIoArgs {
     uint32_t kbits = 0;                       // log2 block length of NTT_BLOCKED_TW
     uint32_t batch = 1;                       // number of transforms in the batch (layout multiplier)
     uint64_t row0 = 0;                        // first row index of the batch inside the large transform
+    // coset transforms (plain layout, one transform): x[i] *= k^i at the first pass's load (forward) or k^-i at the last pass's store
+    // (inverse), from the plan's two-level power table -- the scaling passes coset_fft / coset_ifft (zkp/plonk/utils.py:145-205) run
+    // before / after the transform cost a launch and a read + write of the vector each
+    const Fr *cosA = nullptr, *cosB = nullptr;
+    uint32_t cos_lh = 0;
+    uint32_t cos_in = 0, cos_out = 0;
 };
 
 // Natural-order in/out radix-2 NTT over F_r of size 2^log_n; omega = 5^((r-1)/n).

@@ -138,6 +138,11 @@ __device__ __forceinline__ Fr io_twiddle(const NttIoArgs &io, uint32_t b, uint32
     return fe_mul(io.twA[e & (((uint64_t)1 << io.lh) - 1)], io.twB[e >> io.lh]);
 }
 
+// k^(+-i) from the plan's two-level coset table (< 2r, Montgomery form)
+__device__ __forceinline__ Fr io_coset(const NttIoArgs &io, uint32_t i) {
+    return fe_mul(io.cosA[i & ((1u << io.cos_lh) - 1u)], io.cosB[i >> io.cos_lh]);
+}
+
 // One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
 // passes (lazy 9-limb form, 36 B); only the first load and the last store use the canonical
 // 32-byte encoding.  LDS: data[9][tile] (limb-major, slots swizzled: swz) | tw[9][2^lp]: the twiddles of stage s,
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             if (IN_CANON) {
                 v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
                 if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
+                if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
             } else {
                 v = in_l[((size_t)b << P.L) + i];
             }
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             if (IN_CANON) {
                 v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
                 if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
+                if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
             } else {
                 v = in_l[((size_t)b << P.L) + i];
             }
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             if (P.apply_scale) x = fe_mul(x, scale);
             const uint32_t oidx = (k1_base + ca) + ((kmid + (k << lmid_tot)) << P.l1), b = bbase + cb;
             if (OUT_L == NTT_BLOCKED_TW) x = fe_mul(x, io_twiddle(io, b, oidx));   // 2 * 2 < 169  ->  < 2r
+            if (OUT_L == NTT_PLAIN && io.cos_out) x = fe_mul(x, io_coset(io, oidx));
             st_canon_2r(out_c + io_addr<OUT_L>(P.L, io, b, oidx) * 8, x);
         }
     }
@@ -433,16 +441,23 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
     if (batch == 0) return;
     if (coset_shift && batch != 1) throw std::runtime_error("zk_ntt: coset shifts are not available for batched transforms");
     uint32_t *data = static_cast<uint32_t *>(d_data);
-    const unsigned blocks_sc = (unsigned)((n + 255) / 256);
-    if (coset_shift && !inverse) {
-        coset_tables(coset_shift, false);
-        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_[0].as<Fr>(), cosB_[0].as<Fr>(), lh_, n);
+    NttIoArgs io;
+    if (coset_shift) {
+        // the scaling by k^i (before a forward transform) / k^-i (after an inverse one) rides in the first pass's loads / the last
+        // pass's stores; a transform with no pass at all (n = 1) keeps the separate kernel
+        const int d = inverse ? 1 : 0;
+        coset_tables(coset_shift, inverse);
+        if (L_ == 0) {
+            hipLaunchKernelGGL(fr_scale_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, cosA_[d].as<Fr>(), cosB_[d].as<Fr>(), lh_, n);
+        } else {
+            io.cosA = cosA_[d].as<Fr>();
+            io.cosB = cosB_[d].as<Fr>();
+            io.cos_lh = lh_;
+            io.cos_in = inverse ? 0u : 1u;
+            io.cos_out = inverse ? 1u : 0u;
+        }
     }
-    launch_passes(d_data, d_data, inverse, batch, NTT_PLAIN, NTT_PLAIN, NttIoArgs(), st);
-    if (coset_shift && inverse) {
-        coset_tables(coset_shift, true);
-        hipLaunchKernelGGL(fr_scale_powers_kernel, dim3(blocks_sc), dim3(256), 0, st, data, cosA_[1].as<Fr>(), cosB_[1].as<Fr>(), lh_, n);
-    }
+    launch_passes(d_data, d_data, inverse, batch, NTT_PLAIN, NTT_PLAIN, io, st);
     ZK_HIP(hipGetLastError());
 }
 
