@@ -156,6 +156,11 @@ int zk_ntt_plan_destroy(zk_ntt_plan *plan);
 /* In-place transform of a DEVICE buffer of n*4 limbs.  Enqueues on `stream` and returns without
  * synchronising.  coset_shift is a HOST pointer (nullable). */
 int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t coset_shift[4], void *stream);
+/* The same transform from d_in to d_out (DEVICE buffers; d_out == d_in allowed) of an input that is zero from element in_len on: only
+ * the first min(in_len, n) elements of d_in are read.  What Polynomial.from_evaluations / evaluate-on-a-larger-domain do with a
+ * coefficient list shorter than the domain (zkp/plonk/polynomial.py:263-285, 292-341; the coset form zkp/plonk/utils.py:145-177)
+ * without the zero fill and the copy into a domain-sized buffer. */
+int zk_ntt_dev_padded(zk_ntt_plan *plan, const void *d_in, void *d_out, size_t in_len, int inverse, const uint64_t coset_shift[4], void *stream);
 /* `batch` independent transforms of the plan's size stored back to back in d_data (no coset shift). */
 int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream);
 /* Batched transform between two DEVICE buffers whose layouts are those of the four-step (multi-GPU) transform, so that the

@@ -610,6 +610,15 @@ int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t cose
         return ZK_OK;
     });
 }
+int zk_ntt_dev_padded(zk_ntt_plan *plan, const void *d_in, void *d_out, size_t in_len, int inverse, const uint64_t coset_shift[4], void *stream) {
+    return guarded([&] {
+        if (!plan || !d_out || (in_len && !d_in)) return invalid("zk_ntt_dev_padded: null pointer");
+        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev_padded")) return rc;
+        if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_dev_padded: coset_shift must be a canonical non-zero element of F_r");
+        plan->impl->run_padded(d_in, d_out, in_len, inverse != 0, coset_shift, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream) {
     return guarded([&] {
         if (!plan || (batch && !d_data)) return invalid("zk_ntt_dev_batch: null pointer");

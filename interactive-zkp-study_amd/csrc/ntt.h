@@ -43,6 +43,7 @@ struct NttIoArgs {
     const Fr *cosA = nullptr, *cosB = nullptr;
     uint32_t cos_lh = 0;
     uint32_t cos_in = 0, cos_out = 0;
+    uint32_t in_len = 0xffffffffu;            // plain first-pass loads: elements from in_len on are zero and are not read (zero-padded input)
 };
 
 // Natural-order in/out radix-2 NTT over F_r of size 2^log_n; omega = 5^((r-1)/n).
@@ -52,6 +53,9 @@ class NttPlan {
     // In-place transform of the device buffer (n * 32 bytes, canonical elements).  Enqueues only.
     // `batch` > 1: that many independent transforms stored back to back (no coset shift).
     void run(void *d_data, bool inverse, const uint64_t coset_shift[4], hipStream_t st, unsigned batch = 1);
+    // One transform from d_in to d_out (d_out == d_in allowed): only the first in_len elements of d_in are read, the rest of the input
+    // counts as zero -- a polynomial of in_len coefficients evaluated on a larger domain needs neither the zero fill nor the copy.
+    void run_padded(const void *d_in, void *d_out, size_t in_len, bool inverse, const uint64_t coset_shift[4], hipStream_t st);
     // Batched transform between two buffers with the layouts above (in_layout read by the first pass, out_layout written by the
     // last).  `big` supplies w_N for NTT_BLOCKED_TW (the plan of the large transform; tw_inverse picks w_N^-1).  d_out may be
     // d_in only when both layouts are NTT_PLAIN.

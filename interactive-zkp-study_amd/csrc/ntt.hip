@@ -188,9 +188,13 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             const uint32_t i = base_addr + (j << P.sp) + ca, b = bbase + cb;
             Fr v;
             if (IN_CANON) {
-                v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
-                if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
-                if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
+                if (IN_L == NTT_PLAIN && i >= io.in_len) {
+                    v = Fr::zero();                                                     // zero-padded input: not read
+                } else {
+                    v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
+                    if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
+                    if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
+                }
             } else {
                 v = in_l[((size_t)b << P.L) + i];
             }
@@ -213,9 +217,13 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             const uint32_t i = ((k1_base + ca) << (P.L - P.l1)) + (mid_in << lp) + j, b = bbase + cb;
             Fr v;
             if (IN_CANON) {
-                v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
-                if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
-                if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
+                if (IN_L == NTT_PLAIN && i >= io.in_len) {
+                    v = Fr::zero();                                                     // zero-padded input: not read
+                } else {
+                    v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
+                    if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
+                    if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
+                }
             } else {
                 v = in_l[((size_t)b << P.L) + i];
             }
@@ -458,6 +466,29 @@ void NttPlan::run(void *d_data, bool inverse, const uint64_t coset_shift[4], hip
         }
     }
     launch_passes(d_data, d_data, inverse, batch, NTT_PLAIN, NTT_PLAIN, io, st);
+    ZK_HIP(hipGetLastError());
+}
+
+void NttPlan::run_padded(const void *d_in, void *d_out, size_t in_len, bool inverse, const uint64_t coset_shift[4], hipStream_t st) {
+    const size_t n = (size_t)1 << L_;
+    NttIoArgs io;
+    io.in_len = (uint32_t)std::min<size_t>(in_len, n);
+    if (L_ == 0) {   // no pass to ride in: copy (or zero) the one element, then the in-place path
+        if (io.in_len == 0) ZK_HIP(hipMemsetAsync(d_out, 0, 32, st));
+        else if (d_in != d_out) ZK_HIP(hipMemcpyAsync(d_out, d_in, 32, hipMemcpyDeviceToDevice, st));
+        run(d_out, inverse, coset_shift, st);
+        return;
+    }
+    if (coset_shift) {
+        const int d = inverse ? 1 : 0;
+        coset_tables(coset_shift, inverse);
+        io.cosA = cosA_[d].as<Fr>();
+        io.cosB = cosB_[d].as<Fr>();
+        io.cos_lh = lh_;
+        io.cos_in = inverse ? 0u : 1u;
+        io.cos_out = inverse ? 1u : 0u;
+    }
+    launch_passes(d_in, d_out, inverse, 1, NTT_PLAIN, NTT_PLAIN, io, st);
     ZK_HIP(hipGetLastError());
 }
 

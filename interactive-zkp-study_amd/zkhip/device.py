@@ -128,6 +128,12 @@ class NttPlan:
         _lib.check(_lib.load().zk_ntt_dev(self._h, d_data, 1 if inverse else 0, None if k is None else _lib.ptr(k), stream))
 
 
+    def run_padded(self, d_in, d_out, in_len, inverse=False, coset_shift=None, stream=0):
+        """The transform of an input that is zero from element in_len on, from d_in to d_out (may be the same buffer): only the
+        first in_len elements of d_in are read (zk_ntt_dev_padded) -- no zero fill, no copy into a domain-sized buffer."""
+        k = None if coset_shift is None else _lib.ints_to_limbs([int(coset_shift)])
+        _lib.check(_lib.load().zk_ntt_dev_padded(self._h, d_in, d_out, int(in_len), 1 if inverse else 0, None if k is None else _lib.ptr(k), stream))
+
     def run_batch(self, d_data, batch, inverse=False, stream=0):
         """`batch` independent transforms stored back to back in d_data (zk_ntt_dev_batch)."""
         _lib.check(_lib.load().zk_ntt_dev_batch(self._h, d_data, int(batch), 1 if inverse else 0, stream))

@@ -215,26 +215,20 @@ class ScaleProver:
         #   A: [1, r, 0]    B1: [0, 0, 1]    B2: [1, s]    merged proof_C query (bound CRS): [s, r*s, r]
         self.h_consts.numpy().view(np.uint64)[:] = _lib.ints_to_limbs([1, r, 0, 1, s, s, r * s % R, r])
         self.d_consts.copy_(self.h_consts, non_blocking=True)
-        if ua.data_ptr() != d_a.data_ptr():
-            ua.copy_(d_a)
-        if ub.data_ptr() != d_b.data_ptr():
-            ub.copy_(d_b)
         self.ext_a[m:] = self.d_consts[0:3]
         self.ext_b2[m:] = self.d_consts[3:5]
         if not self.bound:
             self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
-        # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.): 3 inverse NTTs
-        for d in (ua, ub, d_c):
-            self.ntt.run(d.data_ptr(), True, None, st)
+        # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.): 3 inverse NTTs, written where the MSMs read them (the
+        # transforms run from one buffer to another: zk_ntt_dev_padded -- no copies)
+        for src, dst in ((d_a, ua), (d_b, ub), (d_c, d_c)):
+            self.ntt.run_padded(src.data_ptr(), dst.data_ptr(), m, True, None, st)
         self.ext_b2[:m].copy_(ub)
         # H = (A*B - C) / Z on the coset 5*H: 3 coset NTTs + pointwise quotient + 1 coset inverse NTT.  The transforms go
         # FIRST: an accumulate kernel fills every wavefront slot a CU frees, so NTT workgroups queued behind an MSM would
         # wait for its whole grid, the H query would start last and finish alone.
-        ca.copy_(ua)
-        cb.copy_(ub)
-        cc.copy_(d_c)
-        for d in (ca, cb, cc):
-            self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
+        for src, dst in ((ua, ca), (ub, cb), (d_c, cc)):
+            self.ntt.run_padded(src.data_ptr(), dst.data_ptr(), m, False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
         if self.bound:

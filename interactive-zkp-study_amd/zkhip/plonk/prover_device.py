@@ -113,19 +113,16 @@ class DevicePlonk:
             out = self._zeros(self.n + PAD)
         else:
             out[self.n:].zero_()
-        out[:self.n] = evals
-        self.ntt_n.run(out.data_ptr(), True, None, self.st)
+        self.ntt_n.run_padded(evals.data_ptr(), out.data_ptr(), self.n, True, None, self.st)   # evals -> out[:n], no copy
         return out
 
     def _coset(self, coef, out=None):
         """Coefficient buffer -> evaluations on the coset k*H' (size, 4), into `out` when given."""
         if out is None:
-            out = self._zeros(self.size)
-        else:
-            out.zero_()
+            out = _torch().empty((self.size, 4), dtype=_torch().int64, device="cuda")
         m = min(coef.shape[0], self.size)
-        out[:m] = coef[:m]
-        self.ntt_big.run(out.data_ptr(), False, COSET_K, self.st)
+        # the coefficients beyond m count as zero and are not read: neither a zero fill of the 4n-point buffer nor a copy into it
+        self.ntt_big.run_padded(coef.data_ptr(), out.data_ptr(), m, False, COSET_K, self.st)
         return out
 
     def _commit(self, coef, count):

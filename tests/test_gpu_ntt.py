@@ -71,6 +71,35 @@ def test_coset_ntt_vs_oracle(L, k):
     assert np.array_equal(ntt(got, inverse=True, k=k), X)
 
 
+@pytest.mark.parametrize("L,m", [(0, 0), (0, 1), (3, 5), (10, 1), (10, 700), (12, 1024), (12, 4096), (17, 40000), (18, 0)])
+def test_padded_transform_equals_the_zero_filled_one(L, m):
+    """zk_ntt_dev_padded: an input that is zero from element m on, read from one buffer and written to another (or in place), with
+    and without the coset shift, both directions -- the same vectors as the in-place transform of the explicitly zero-padded copy
+    (itself checked against the oracle above).  The elements behind m hold garbage that must not be read."""
+    import torch
+    rng = np.random.default_rng(500 + L + m)
+    n = 1 << L
+    X = _fast_rand(rng, n)
+    Z = X.copy()
+    Z[m:] = 0
+    d_in = torch.from_numpy(X.view(np.int64)).cuda()            # garbage (non-zero) behind m
+    plan = NttPlan(L)
+    st = torch.cuda.current_stream().cuda_stream
+    for inverse in (False, True):
+        for k in (None, 5):
+            want = ntt(Z, inverse=inverse, k=k)
+            d_out = torch.full((n, 4), -1, dtype=torch.int64, device="cuda")
+            plan.run_padded(d_in.data_ptr(), d_out.data_ptr(), m, inverse, k, st)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want), (inverse, k)
+            assert np.array_equal(d_in.cpu().numpy().view(np.uint64), X)          # the input is left alone
+            d_same = d_in.clone()
+            plan.run_padded(d_same.data_ptr(), d_same.data_ptr(), m, inverse, k, st)     # in place
+            torch.cuda.synchronize()
+            assert np.array_equal(d_same.cpu().numpy().view(np.uint64), want), ("in place", inverse, k)
+    plan.close()
+
+
 def test_ntt_edge_values_and_errors():
     n = 16
     X = co.to_limbs([0, 1, o.R - 1, o.R - 2] * 4)
