@@ -213,7 +213,10 @@ int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals,
  *                           from the last element down (suffix sums / products).  Synthetic division by (x - z):
  *                           q[i] = z^-(i+1) * sum_{j>i} c[j] z^j;  grand product: prefix products of the numerators
  *                           times suffix products of the denominators over their total.
- * A zk_frvec holds the scratch of the last two (power tables, per-level chunk totals); one per thread and stream of use:
+ *   zk_fr_eval_dev          out[j] = sum_i coefs[j][i] * point^i for k <= 8 polynomials at ONE point (Polynomial.evaluate,
+ *                           polynomial.py:85-106, called once per opening in zkp/plonk/prover/round4.py:40-79): one pass over the
+ *                           coefficients; d_out: k canonical elements on the DEVICE.
+ * A zk_frvec holds the scratch of the last three (power tables, per-level chunk totals, block sums); one per thread and stream of use:
  * every call rewrites it with kernels on `stream` (nothing is built on the host, no call synchronises), so only stream
  * order keeps consecutive calls apart.
  */
@@ -235,6 +238,8 @@ int zk_fr_lincomb_dev(void *d_out, const void *const *d_in /* k HOST-side array 
 int zk_fr_mul_dev(void *d_out, const void *d_a, const void *d_b, size_t n, void *stream);
 int zk_fr_scale_powers_dev(zk_frvec *ws, void *d_data, size_t n, const uint64_t base[4], void *stream);
 int zk_fr_scan_dev(zk_frvec *ws, void *d_data, size_t n, int op, int reverse, void *stream);
+int zk_fr_eval_dev(zk_frvec *ws, const void *const *d_coefs /* k HOST-side array of device pointers */, const size_t *counts /* k */, unsigned k,
+                   const uint64_t point[4], void *d_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fixed-base batch scalar multiplication out[i] = scalars[i] * base  (HOST buffers).

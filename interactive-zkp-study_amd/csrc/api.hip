@@ -753,6 +753,17 @@ int zk_fr_scan_dev(zk_frvec *ws, void *d_data, size_t n, int op, int reverse, vo
         return ZK_OK;
     });
 }
+int zk_fr_eval_dev(zk_frvec *ws, const void *const *d_coefs, const size_t *counts, unsigned k, const uint64_t point[4], void *d_out, void *stream) {
+    return guarded([&] {
+        if (!ws || !point || (k && (!d_coefs || !counts || !d_out))) return invalid("zk_fr_eval_dev: null pointer");
+        for (unsigned j = 0; j < k; j++)
+            if (counts[j] && !d_coefs[j]) return invalid("zk_fr_eval_dev: null pointer");
+        if (!scalars_canonical(point, 1)) return invalid("zk_fr_eval_dev: point not canonical (>= r)");
+        if (int rc = check_plan_device(ws->device, "zk_fr_eval_dev")) return rc;
+        ws->impl.eval(d_coefs, counts, k, point, d_out, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_fr_quotient_dev(void *d_out, const void *d_a, const void *d_b, const void *d_c, const uint64_t zinv[4], size_t n, void *stream) {
     return guarded([&] {
         if (!d_out || !d_a || !d_b || !d_c || !zinv) return invalid("zk_fr_quotient_dev: null pointer");

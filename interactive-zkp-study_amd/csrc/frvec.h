@@ -28,6 +28,8 @@ struct FrVecScratch {
     void scale_powers(void *d_data, size_t n, const uint64_t base[4], hipStream_t st);
     // in-place inclusive scan under + (mul == false) or * (mul == true); reverse: from the last element down
     void scan(void *d_data, size_t n, bool mul, bool reverse, hipStream_t st);
+    // out[j] = sum_i coefs[j][i] * point^i for k <= 8 polynomials (counts[j] coefficients each); d_out: k canonical elements
+    void eval(const void *const *d_coefs, const size_t *counts, unsigned k, const uint64_t point[4], void *d_out, hipStream_t st);
 };
 
 }  // namespace zk

@@ -226,6 +226,71 @@ template <bool MUL, bool REV> void scan_impl(uint32_t *x, size_t n, hipStream_t 
     ZK_HIP(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------ p(z) for up to 8 polynomials
+// out[j] = sum_i c_j[i] z^i (Polynomial.evaluate, zkp/plonk/polynomial.py:85-106, is Horner's rule: n dependent products).  Thread t of
+// block b starts at element b * 256 + t with z^i from the two-level table (one product) and walks on in steps of EVAL_BLOCKS * 256
+// elements, multiplying its power by z^stride: two products per element, consecutive lanes on consecutive elements, no table in
+// the loop.  The coefficients are plain, the powers Montgomery: mont_mul(c, z^i R) = c z^i.  Block sums through LDS, one partial per
+// block and polynomial; the second kernel adds a polynomial's partials.
+constexpr int EVAL_NT = 256, EVAL_BLOCKS = 256, EVAL_MAX = 8;
+struct EvalArgs {
+    const uint32_t *coef[EVAL_MAX];
+    uint32_t count[EVAL_MAX];
+    Fr zstride;   // z^(EVAL_BLOCKS * EVAL_NT), Montgomery form
+};
+__device__ __forceinline__ Fr eval_block_sum(Fr acc, uint32_t (*sh)[EVAL_NT]) {
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NL; i++) sh[i][t] = acc.l[i];
+    __syncthreads();
+    for (uint32_t d = EVAL_NT / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+            Fr a, b;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                a.l[i] = sh[i][t];
+                b.l[i] = sh[i][t + d];
+            }
+            ZK_DBG(a.vb = 2; a.lmax = 1; b.vb = 2; b.lmax = 1;)
+            a = fe_add(a, b);
+            fe_wreduce<4>(a);
+#pragma unroll
+            for (int i = 0; i < NL; i++) sh[i][t] = a.l[i];
+        }
+        __syncthreads();
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = sh[i][0];
+    return r;
+}
+__global__ __launch_bounds__(EVAL_NT) void fr_eval_partial_kernel(EvalArgs A, const Fr *__restrict__ tabA, const Fr *__restrict__ tabB,
+                                                                 uint32_t *__restrict__ partial) {
+    __shared__ uint32_t sh[NL][EVAL_NT];
+    const uint32_t j = blockIdx.y, n = A.count[j];
+    const uint32_t *__restrict__ c = A.coef[j];
+    Fr acc = Fr::zero();
+    uint32_t i = blockIdx.x * EVAL_NT + threadIdx.x;
+    if (i < n) {
+        Fr pw = fe_mul(tabA[threadIdx.x], tabB[blockIdx.x]);          // z^i = z^t * (z^256)^b, Montgomery form, < 2r
+        for (;;) {
+            acc = fe_add(acc, fe_mul(ldc(c + (size_t)i * 8), pw));     // < 2r + 2r
+            fe_wreduce<4>(acc);
+            i += EVAL_BLOCKS * EVAL_NT;
+            if (i >= n || i < EVAL_BLOCKS * EVAL_NT) break;            // (the second test: 32-bit wrap-around)
+            pw = fe_mul(pw, A.zstride);
+        }
+    }
+    const Fr tot = eval_block_sum(acc, sh);
+    if (threadIdx.x == 0) stc(partial + ((size_t)j * EVAL_BLOCKS + blockIdx.x) * 8, tot);
+}
+__global__ __launch_bounds__(EVAL_NT) void fr_eval_final_kernel(const uint32_t *__restrict__ partial, uint32_t *__restrict__ out) {
+    __shared__ uint32_t sh[NL][EVAL_NT];
+    static_assert(EVAL_BLOCKS == EVAL_NT, "one partial per thread");
+    const Fr tot = eval_block_sum(ldc(partial + ((size_t)blockIdx.x * EVAL_BLOCKS + threadIdx.x) * 8), sh);
+    if (threadIdx.x == 0) stc(out + (size_t)blockIdx.x * 8, tot);
+}
+
 HFr host_fr(const uint64_t v[4]) {
     HFr a;
     memcpy(a.l, v, 32);
@@ -301,6 +366,34 @@ void FrVecScratch::scale_powers(void *d_data, size_t n, const uint64_t base[4], 
                        (uint32_t)na, (uint32_t)nb);
     hipLaunchKernelGGL(fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_data), tables.as<Fr>(),
                        tables.as<Fr>() + na, lh, n);
+    ZK_HIP(hipGetLastError());
+}
+
+void FrVecScratch::eval(const void *const *d_coefs, const size_t *counts, unsigned k, const uint64_t point[4], void *d_out, hipStream_t st) {
+    if (k == 0) return;
+    if (k > (unsigned)EVAL_MAX) throw std::runtime_error("zk_fr_eval_dev: at most 8 polynomials per call");
+    EvalArgs A;
+    memset(&A, 0, sizeof(A));
+    for (unsigned j = 0; j < k; j++) {
+        if (counts[j] >= ((size_t)1 << 31)) throw std::runtime_error("zk_fr_eval_dev: polynomial too long");
+        A.coef[j] = static_cast<const uint32_t *>(d_coefs[j]);
+        A.count[j] = (uint32_t)counts[j];
+    }
+    const HFr g = fe_to_mont(host_fr(point));
+    HFr gh = g;
+    for (int i = 0; i < 8; i++) gh = fe_sqr(gh);     // z^256
+    HFr gs = gh;
+    for (int i = 0; i < 8; i++) gs = fe_sqr(gs);     // z^65536 = z^(EVAL_BLOCKS * EVAL_NT)
+    A.zstride = gs.to_dev();
+    // tables: z^t (256) | (z^256)^b (256) | partial sums (8 * 256 canonical elements): inside the buffer scale_powers sizes once
+    const size_t cap = (size_t)2 << 14;
+    if (tables.bytes < cap * sizeof(Fr)) tables.alloc(cap * sizeof(Fr));
+    Fr *tab = tables.as<Fr>();
+    uint32_t *partial = reinterpret_cast<uint32_t *>(tab + 2 * EVAL_NT);
+    static_assert((2 * EVAL_NT) * sizeof(Fr) + (size_t)EVAL_MAX * EVAL_BLOCKS * 32 <= ((size_t)2 << 14) * sizeof(Fr), "scratch layout");
+    hipLaunchKernelGGL(fr_power_table_kernel, dim3(2), dim3(256), 0, st, tab, g.to_dev(), gh.to_dev(), (uint32_t)EVAL_NT, (uint32_t)EVAL_BLOCKS);
+    hipLaunchKernelGGL(fr_eval_partial_kernel, dim3(EVAL_BLOCKS, k), dim3(EVAL_NT), 0, st, A, tab, tab + EVAL_NT, partial);
+    hipLaunchKernelGGL(fr_eval_final_kernel, dim3(k), dim3(EVAL_NT), 0, st, partial, static_cast<uint32_t *>(d_out));
     ZK_HIP(hipGetLastError());
 }
 

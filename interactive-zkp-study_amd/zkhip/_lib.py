@@ -76,6 +76,7 @@ _PROTOS = {
     "zk_fr_mul_dev": (ctypes.c_int, [_VP, _VP, _VP, _SZ, _VP]),
     "zk_fr_scale_powers_dev": (ctypes.c_int, [_VP, _VP, _SZ, _VP, _VP]),
     "zk_fr_scan_dev": (ctypes.c_int, [_VP, _VP, _SZ, ctypes.c_int, ctypes.c_int, _VP]),
+    "zk_fr_eval_dev": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_uint, _VP, _VP, _VP]),
     "zk_fixed_base_g1": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_fixed_base_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_group_op": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, _VP, _SZ, _VP]),

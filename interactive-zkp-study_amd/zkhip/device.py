@@ -197,6 +197,15 @@ class FrVec:
         b = _lib.ints_to_limbs([int(base)])
         _lib.check(_lib.load().zk_fr_scale_powers_dev(self._h, d_data, n, _lib.ptr(b), stream))
 
+    def eval(self, items, point, d_out, stream=0):
+        """d_out[j] = sum_i coefs_j[i] * point^i for items = [(d_coefs, count), ...] (at most 8) at ONE point (zk_fr_eval_dev):
+        one pass over the coefficients; the k values stay on the device (d_out: k canonical elements)."""
+        k = len(items)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[ctypes.c_void_p(int(p)) for p, _ in items])
+        cnt = (ctypes.c_size_t * max(k, 1))(*[int(c) for _, c in items])
+        z = _lib.ints_to_limbs([int(point)])
+        _lib.check(_lib.load().zk_fr_eval_dev(self._h, ptrs, cnt, k, _lib.ptr(z), d_out, stream))
+
     def scan(self, d_data, n, product=False, reverse=False, stream=0):
         """In-place inclusive scan: running sums (product=False) or products; reverse: from the last element down."""
         _lib.check(_lib.load().zk_fr_scan_dev(self._h, d_data, n, 1 if product else 0, 1 if reverse else 0, stream))

@@ -153,17 +153,14 @@ class DevicePlonk:
         return self._evaluate_many([(coef, count)], point)[0]
 
     def _evaluate_many(self, items, point):
-        """[(coef, count)] -> [p(point)]: the powers of the point are built once, every evaluation is an element-wise
-        product and a running sum, and all values come back in one copy."""
-        cmax = max(c for _, c in items)
-        pw, tmp, res = self.buf["pw"], self.buf["etmp"], self.small[:len(items)]
-        pw[:cmax] = self.ones[:cmax]
-        self.fv.scale_powers(pw.data_ptr(), cmax, int(point), self.st)
-        for k, (coef, count) in enumerate(items):
-            self._mul(tmp, coef, pw, count)
-            self.fv.scan(tmp.data_ptr(), count, False, False, self.st)
-            res[k:k + 1] = tmp[count - 1:count]
-        return [FR(v) for v in _lib.limbs_to_ints(res.cpu().numpy().view(np.uint64))]
+        """[(coef, count)] -> [p(point)]: one pass over the coefficients of all of them (zk_fr_eval_dev), all values back in one copy."""
+        out = []
+        for lo in range(0, len(items), 8):
+            part = items[lo:lo + 8]
+            res = self.small[:len(part)]
+            self.fv.eval([(coef.data_ptr(), count) for coef, count in part], int(point) % R, res.data_ptr(), self.st)
+            out += [FR(v) for v in _lib.limbs_to_ints(res.cpu().numpy().view(np.uint64))]
+        return out
 
     def _divide_linear(self, coef, count, point, q):
         """Quotient of p(x) / (x - point) into q: count - 1 coefficients (the remainder p(point) is dropped; rows of q

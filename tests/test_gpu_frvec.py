@@ -116,3 +116,37 @@ def test_synthetic_division_and_grand_product():
     # Gs[i] / G_total = 1 / prod_{j<i} g_j
     assert got == want
     fv.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 65535, 65536, 65537, 200003])
+def test_eval_at_a_point(n):
+    """zk_fr_eval_dev: p(z) = sum_i c_i z^i for up to eight polynomials of different lengths at one point, against Horner's rule
+    on Python integers (Polynomial.evaluate, zkp/plonk/polynomial.py:85-106); lengths around the 256-element blocks and the
+    65536-element stride, z = 0, 1, r - 1 and random points, an empty polynomial, more than eight refused."""
+    rng = np.random.default_rng(900 + n)
+    counts = [n, max(n - 1, 0), min(n, 7), 0, n, n // 2 + 1, n, 1]
+    base = rand_fr_limbs(rng, 4099)
+    polys = [np.ascontiguousarray(np.tile(base, (c // 4099 + 1, 1))[:max(c, 1)]) for c in counts]
+    polys[4] = polys[4].copy()
+    polys[4][0] = 0
+    polys[4][-1] = _lib.ints_to_limbs([R - 1])[0]
+    ints = [_lib.limbs_to_ints(p)[:c] for p, c in zip(polys, counts)]
+    d = [_dev(p) for p in polys]
+    out = _dev(np.zeros((8, 4), dtype=np.uint64))
+    fv = FrVec()
+    for z in (0, 1, R - 1, int.from_bytes(rng.bytes(32), "little") % R, 5):
+        for k in (8, 3, 1):
+            fv.eval([(t.data_ptr(), c) for t, c in zip(d[:k], counts[:k])], z, out.data_ptr())
+            got = _ints(out)[:k]
+            want = []
+            for cs in ints[:k]:
+                acc = 0
+                for c in reversed(cs):
+                    acc = (acc * z + c) % R
+                want.append(acc)
+            assert got == want, (z, k)
+    with pytest.raises(_lib.ZkhipError):
+        fv.eval([(t.data_ptr(), c) for t, c in zip(d, counts)] + [(d[0].data_ptr(), 1)], 5, out.data_ptr())
+    with pytest.raises(_lib.ZkhipError):
+        fv.eval([(d[0].data_ptr(), 1)], R, out.data_ptr())      # point not canonical
+    fv.close()
