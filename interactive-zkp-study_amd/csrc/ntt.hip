@@ -243,18 +243,8 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
         } else {
             ntt_round<1, true>(data, tw, tile, ntw, lp, g, sh);  // a single stage is only ever the last one
         }
-        // A radix-4 round whose groups span <= 256 slots (top stage s_hi with s_hi + 1 + g <= 8) reads and writes, in a full
-        // 2^10-element tile with one group per thread, only the 256 slots [256 w, 256 w + 256) of its own wavefront w (group gi ->
-        // block (gi >> g) >> s_lo of 2^(s_hi + 1 + g) slots; the swizzle stays inside 32-slot runs), and so does every round below
-        // it: between two such rounds the workgroup barrier is not needed -- LDS serves one wavefront's accesses in order.
-        const bool wave_local = R == 2 && tile == 4u * NTT_NT && (uint32_t)sh + 1u + g <= 8u && !last && sh - R != 0;
         sh -= R;
-        if (wave_local) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            __syncthreads();
-        }
+        __syncthreads();
     }
 
     if (!FINAL) {
