@@ -406,7 +406,8 @@ def test_g1_msm_2pow26_one_gpu_closed_form():
     through the plan's lanes, ~7 GB of inputs.  Scalars are drawn on the device (uniform below r), bases are
     P_i = (k0 + i d) G1, the result must be (sum s_i (k0 + i d)) G1 computed by the oracle; a few bases and the first
     scalars' canonicity are spot-checked on the host.  The eight-rank split of the same MSM is a sum of such partials:
-    the second half checks that two half-size partial sums fold to the same point (zk_msm_fold_partials)."""
+    the second half checks that two half-size partial sums fold to the same point (zk_msm_fold_partials), and then that the
+    eight 2^23-point chunks of the eight-rank split (shard_range) fold, in rank order, to it as well."""
     import torch
     from zkhip.distributed import fold_partials
     from zkhip.synthetic import ARITH_D, ARITH_K0, arithmetic_dot_device, arithmetic_points, random_scalars_device
@@ -429,6 +430,16 @@ def test_g1_msm_2pow26_one_gpu_closed_form():
     parts = np.stack([plan.run_partial(dS[:half].data_ptr(), dP[:half].data_ptr(), half, st),
                       plan.run_partial(dS[half:].data_ptr(), dP[half:].data_ptr(), half, st)])
     assert fold_partials(_lib.GROUP_G1, parts) == want
+    # configs[4] itself, minus the wire: the eight ranks' chunks exactly as zkhip.distributed cuts them (shard_range: contiguous,
+    # 2^23 points each), every chunk down to its 128-byte XYZZ partial, the eight partials folded in rank order -- what every rank
+    # does with the all-gathered partials (the all-gather is covered by the world-size-2 / 8 gloo tests and the 4-rank rehearsal)
+    from zkhip.distributed import shard_range
+    parts8 = []
+    for rank in range(8):
+        lo, hi = shard_range(n, rank, 8)
+        assert hi - lo == 1 << 23
+        parts8.append(plan.run_partial(dS[lo:hi].data_ptr(), dP[lo:hi].data_ptr(), hi - lo, st))
+    assert fold_partials(_lib.GROUP_G1, np.stack(parts8)) == want
     plan.close()
 
 
