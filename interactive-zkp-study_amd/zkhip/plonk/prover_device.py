@@ -4,12 +4,12 @@ Same protocol, transcript, blinding degrees and proof fields as zkhip/plonk/prov
 zkp/plonk/prover/round1..5.py on Python lists and is what the reference-sized circuits use); here the columns,
 selector / permutation polynomials and the SRS are device buffers and the rounds are sequences of backend calls:
 
-  interpolation, coset evaluation      zk_ntt_dev (NttPlan)
+  interpolation, coset evaluation      zk_ntt_dev_padded (NttPlan.run_padded: coefficients -> a larger domain, no zero fill / copy)
   commitments                          zk_msm_submit / collect (MsmPlan, up to three in flight)
   a + beta*id + gamma, r(x), ...       zk_fr_lincomb_dev, zk_fr_mul_dev
   round-3 quotient on the coset        zk_plonk_quotient_dev (one fused pass over 15 vectors)
   grand product z                      prefix products of the numerators, suffix products of the denominators (zk_fr_scan_dev)
-  p(zeta)                              zk_fr_scale_powers_dev + running sum
+  p(zeta) of all openings of a round   zk_fr_eval_dev (one pass over the coefficients)
   (p(x) - p(z)) / (x - z)              q[i] = z^-(i+1) * sum_{j>i} c[j] z^j: scale, suffix sums, scale
 
 The host only hashes the transcript and handles the ~20 scalars between rounds.  With the same blinding scalars the
@@ -99,7 +99,7 @@ class DevicePlonk:
         self.work = [self._zeros(self.size) for _ in range(6)]   # per-proof coset buffers: a, b, c, z, z(omega x), t
         # per-proof coefficient / scratch vectors, allocated once: prove() itself allocates nothing on the device, so the
         # caching allocator never has to find (or release and re-acquire) twenty 32 MB blocks in the middle of a proof
-        self.buf = {k: self._zeros(n + PAD) for k in ("w0", "w1", "w2", "z", "num", "den", "tmp", "z_ev", "t0", "t1", "t2", "pw", "etmp",
+        self.buf = {k: self._zeros(n + PAD) for k in ("w0", "w1", "w2", "z", "num", "den", "tmp", "z_ev", "t0", "t1", "t2",
                                                       "r_poly", "numer", "dtmp", "q0", "q1")}
         self.small = self._zeros(16)
 
