@@ -392,6 +392,45 @@ int orc_g1_msm_bucket(const uint64_t *scalars, const uint64_t *points, size_t n,
     return 0;
 }
 
+/* The same textbook bucket method in G2 (proof_b's query, zkp/groth16/proving.py:35-45, at sizes where orc_g2_msm's
+ * per-term double-and-add would take minutes).  Same group element as orc_g2_msm (tests/test_oracle.py). */
+int orc_g2_msm_bucket(const uint64_t *scalars, const uint64_t *points, size_t n, unsigned c, uint64_t out[16]) {
+    ensure_init();
+    if (c < 1 || c > 20) return -1;
+    const unsigned windows = (254 + c - 1) / c;
+    const size_t nb = ((size_t)1 << c) - 1;
+    g2_jac *buckets = (g2_jac *)malloc(sizeof(g2_jac) * nb);
+    g2_jac *pts = (g2_jac *)malloc(sizeof(g2_jac) * (n ? n : 1));
+    if (!buckets || !pts) { free(buckets); free(pts); return -2; }
+    for (size_t i = 0; i < n; i++) g2_load(&pts[i], points + 16 * i);
+    g2_jac total, run, wsum;
+    memset(&total, 0, sizeof(total));
+    for (int w = (int)windows - 1; w >= 0; w--) {
+        for (unsigned d = 0; d < c; d++) g2_dbl(&total, &total);
+        memset(buckets, 0, sizeof(g2_jac) * nb);
+        for (size_t i = 0; i < n; i++) {
+            unsigned d = window_digit(scalars + 4 * i, (unsigned)w * c, c);
+            if (d) g2_add(&buckets[d - 1], &buckets[d - 1], &pts[i]);
+        }
+        memset(&run, 0, sizeof(run));
+        memset(&wsum, 0, sizeof(wsum));
+        for (size_t b = nb; b-- > 0;) {
+            g2_add(&run, &run, &buckets[b]);
+            g2_add(&wsum, &wsum, &run);
+        }
+        g2_add(&total, &total, &wsum);
+    }
+    g2_store(out, &total);
+    free(buckets);
+    free(pts);
+    return 0;
+}
+
+/* Fixed-base batch in G2: out[i] = k_i * P  (sigma22 zkp/groth16/setup.py:65-69) */
+void orc_g2_fixed_base(const uint64_t p[16], const uint64_t *scalars, size_t n, uint64_t *out) {
+    for (size_t i = 0; i < n; i++) orc_g2_mul(p, scalars + 4 * i, out + 16 * i);
+}
+
 /* The same bucket method with the windows spread over `threads` POSIX threads (windows are independent; the window sums
  * are combined by one Horner pass) -- bench.py's "all the cores a one-GPU box gives us" CPU line. */
 typedef struct {

@@ -145,6 +145,26 @@ def g2_msm_arr(scalars, points):
     return O
 
 
+def g2_msm_bucket_arr(scalars, points, c=12):
+    """Bucket-method G2 MSM (orc_g2_msm_bucket), same result as g2_msm_arr; c = window bits."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    O = np.zeros(16, dtype=np.uint64)
+    rc = lib().orc_g2_msm_bucket(_p(scalars), _p(points), ctypes.c_size_t(scalars.shape[0]), ctypes.c_uint(c), _p(O))
+    if rc:
+        raise RuntimeError("orc_g2_msm_bucket failed: %d" % rc)
+    return O
+
+
+def g2_fixed_base_arr(pt, scalars):
+    """out[i] = k_i * pt in G2; scalars (n,4) uint64 -> (n,16) uint64."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    P = g2_to_arr([pt])
+    O = np.zeros((scalars.shape[0], 16), dtype=np.uint64)
+    lib().orc_g2_fixed_base(_p(P), _p(scalars), ctypes.c_size_t(scalars.shape[0]), _p(O))
+    return O
+
+
 def g1_fixed_base_arr(pt, scalars):
     """out[i] = k_i * pt; scalars (n,4) uint64 -> (n,8) uint64."""
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)

@@ -47,3 +47,7 @@ def limb_row(v):
 # implementation, shared with bench.py and tools/ (zkhip/synthetic.py); its host and device forms are checked against
 # Python big integers in tests/test_bench_launcher.py.
 from zkhip.synthetic import arithmetic_dot, arithmetic_points as arithmetic_g1_points  # noqa: E402,F401
+
+
+# Oracle-side expectations for the at-scale Groth16 prover (BASELINE.json configs[3]): oracle/scale_ref.py
+from scale_ref import chain_closed_form_oracle, chain_crs_scalars, chain_witness, lagrange_at  # noqa: E402,F401

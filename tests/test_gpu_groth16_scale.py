@@ -5,9 +5,10 @@ gives (zkp/groth16/test.py:303-325), and H(x) against the oracle's schoolbook mu
 import numpy as np
 import pytest
 
+import c_oracle as co
 import py_ref as o
+from helpers import chain_closed_form_oracle, chain_crs_scalars, chain_witness
 from zkhip import _lib
-from zkhip.field import G1, G2, ec_mul
 from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver, closed_form_scalars
 
 pytestmark = pytest.mark.gpu
@@ -18,21 +19,59 @@ def _dev(ints):
     return torch.from_numpy(_lib.ints_to_limbs(ints).view(np.int64)).cuda()
 
 
+TOXIC = dict(alpha=3926, beta=3604, gamma=2971, delta=1357)
+
+
+def _ints(pt):
+    """A proof point as plain integers: G1 -> (x, y), G2 -> ((x0, x1), (y0, y1)) -- the oracle's point format."""
+    if pt is None:
+        return None
+    if hasattr(pt[0], "coeffs"):
+        return tuple(tuple(int(c) for c in v.coeffs) for v in pt)
+    return (int(pt[0]), int(pt[1]))
+
+
+def _oracle_proof(circ, x_val, w, r, s):
+    """(A*G1, B*G2, C*G1) with the scalars AND the points from the oracle (zkp/groth16/test.py:303-325); nothing of the
+    library's CRS, field layer or group kernels is involved in the expectation."""
+    assert w == chain_witness(circ.consts, circ.t0)
+    A, B, C = chain_closed_form_oracle(circ.consts, w, dict(TOXIC, x=x_val), r, s)
+    return co.g1_mul(o.G1, A), co.g2_mul(o.G2, B), co.g1_mul(o.G1, C)
+
+
+def _check_crs_against_oracle(crs, x_val):
+    """A few elements of every device-built query (zkp/groth16/setup.py:18-69) against the oracle's k*G."""
+    circ = crs.circuit
+    m, W = circ.m, circ.num_wires
+    i12, i14, i15 = [0, 1, m // 3, m - 1], [2, 3, W // 2, W - 2, W - 1], [0, 1, m // 2, m - 2]
+    k12, k14, k15 = chain_crs_scalars(circ.consts, dict(TOXIC, x=x_val), i12, i14, i15)
+    rows = lambda t, idx: t[idx].cpu().numpy().view(np.uint64)
+    assert np.array_equal(rows(crs.d_s12, i12), co.g1_fixed_base_arr(o.G1, co.to_limbs(k12)))
+    assert np.array_equal(rows(crs.d_s22, i12), co.g2_fixed_base_arr(o.G2, co.to_limbs(k12)))
+    assert np.array_equal(rows(crs.d_s14, i14), co.g1_fixed_base_arr(o.G1, co.to_limbs(k14)))
+    assert np.array_equal(rows(crs.d_s15, i15), co.g1_fixed_base_arr(o.G1, co.to_limbs(k15)))
+    assert not rows(crs.d_s14, circ.pub).any()                          # placeholders at the public wires (setup.py:50)
+    t = TOXIC
+    consts = [t["alpha"], t["delta"], t["beta"]]                         # the constant-term bases appended to sigma1_2 / sigma2_2
+    assert np.array_equal(rows(crs.d_s12, [m, m + 1, m + 2]), co.g1_fixed_base_arr(o.G1, co.to_limbs(consts)))
+    assert np.array_equal(rows(crs.d_s22, [m, m + 1]), co.g2_fixed_base_arr(o.G2, co.to_limbs([t["beta"], t["delta"]])))
+
+
 @pytest.mark.parametrize("log_m", [4, 10, 13])
 def test_scale_prover_closed_form(log_m):
     import torch
     circ = ChainCircuit(log_m, seed=3)
-    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 200))
+    x_val = 3721 + (1 << 200)
+    crs = ScaleCRS(circ, x_val=x_val, **TOXIC)
+    _check_crs_against_oracle(crs, x_val)
     w, a, b, c = circ.witness()
     assert all(a[k] * b[k] % o.R == c[k] for k in range(0, circ.m, max(1, circ.m // 64)))  # R1CS satisfied
     prover = ScaleProver(crs)
     r, s = 4106, 4565
     d_a, d_b, d_c, d_w = _dev(a), _dev(b), _dev(c), _dev(w)
     pa, pb, pc, h = prover.prove(d_a, d_b, d_c, d_w, r, s)
-    A, B, C = closed_form_scalars(crs, w, r, s)
-    assert pa == ec_mul(G1, A)
-    assert pb == ec_mul(G2, B)
-    assert pc == ec_mul(G1, C)
+    assert (_ints(pa), _ints(pb), _ints(pc)) == _oracle_proof(circ, x_val, w, r, s)
+    assert closed_form_scalars(crs, w, r, s) == chain_closed_form_oracle(circ.consts, w, dict(TOXIC, x=x_val), r, s)
     # the same proof from the witness alone: A.w, B.w, C.w by the device mat-vec (prove() consumed d_a..d_c in place)
     prover.load_r1cs(circ.r1cs_csr())
     qa, qb, qc, _ = prover.prove_from_witness(d_w, r, s)
@@ -58,12 +97,12 @@ def test_scale_prover_on_a_side_stream():
     a prover that read them from the default stream's point of view would see stale data."""
     import torch
     circ = ChainCircuit(12, seed=5)
-    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 200))
+    x_val = 3721 + (1 << 200)
+    crs = ScaleCRS(circ, x_val=x_val, **TOXIC)
     w, a, b, c = circ.witness()
     prover = ScaleProver(crs)
     prover.load_r1cs(circ.r1cs_csr())
-    A, B, C = closed_form_scalars(crs, w, 4106, 4565)
-    want = (ec_mul(G1, A), ec_mul(G2, B), ec_mul(G1, C))
+    want = _oracle_proof(circ, x_val, w, 4106, 4565)
     side = torch.cuda.Stream()
     staging = _dev(w)
     d_w = torch.zeros_like(staging)
@@ -73,7 +112,7 @@ def test_scale_prover_on_a_side_stream():
             d_w.zero_()
             d_w.copy_(staging)                                  # the witness appears on the side stream only
         got = prover.prove_from_witness(d_w, 4106, 4565, stream=side.cuda_stream)
-        assert got[:3] == want
+        assert tuple(_ints(p) for p in got[:3]) == want
     torch.cuda.synchronize()
 
 
@@ -85,16 +124,16 @@ def test_scale_prover_2pow20_constraints_closed_form():
     log_m = 20
     circ = ChainCircuit(log_m, seed=7)
     w, a, b, c = circ.witness()
-    crs = ScaleCRS(circ, alpha=3926, beta=3604, gamma=2971, delta=1357, x_val=3721 + (1 << 201))
+    x_val = 3721 + (1 << 201)
+    crs = ScaleCRS(circ, x_val=x_val, **TOXIC)
+    _check_crs_against_oracle(crs, x_val)                                # the device-built CRS, a few elements of every query
     prover = ScaleProver(crs)
     prover.load_r1cs(circ.r1cs_csr())
     d_w = _dev(w)
     r, s = 4106, 4565
     pa, pb, pc, h = prover.prove_from_witness(d_w, r, s)
-    A, B, C = closed_form_scalars(crs, w, r, s)
-    assert pa == ec_mul(G1, A)
-    assert pb == ec_mul(G2, B)
-    assert pc == ec_mul(G1, C)
+    # expected points: scalars by the oracle's inverse NTT + Horner, points by the oracle's double-and-add
+    assert (_ints(pa), _ints(pb), _ints(pc)) == _oracle_proof(circ, x_val, w, r, s)
     torch.cuda.synchronize()
     assert torch.equal(prover.abc[0], _dev(a)) and torch.equal(prover.abc[1], _dev(b))   # A.w and B.w of the device mat-vec
     assert (pa, pb, pc) == prover.prove_from_witness(d_w, r, s)[:3]

@@ -143,6 +143,70 @@ def test_g2_msm_skewed_scalars(pattern):
     assert np.array_equal(msm_g2(S, Pts), co.g2_msm_arr(S, Pts))
 
 
+def _g2_bases(K):
+    """P_i = k_i * G2 from the fixed-base kernel, a few of them checked against the oracle's k * G2."""
+    n = K.shape[0]
+    base = co.g2_to_arr([o.G2])
+    Pts = np.zeros((n, 16), dtype=np.uint64)
+    _lib.check(_lib.load().zk_fixed_base_g2(_lib.ptr(base), _lib.ptr(K), n, _lib.ptr(Pts)))
+    idx = [0, 1, n // 2, n - 1]
+    assert np.array_equal(Pts[idx], co.g2_fixed_base_arr(o.G2, K[idx]))
+    return Pts
+
+
+@pytest.mark.parametrize("n", [131072, 131073, (1 << 18) + 77, 1 << 20])
+def test_g2_msm_unbound_closed_form_across_c16_switch(n):
+    """proof_b's query (zkp/groth16/proving.py:35-45) at real sizes, UNBOUND bases: 15-bit windows up to 2^17 points, 16-bit
+    windows above (msm_prepare_kernel<Fp2,16>, G2 cells of full size, the G2 window reduction).  P_i = k_i*G2, so the MSM is
+    (sum s_i k_i) * G2 with the scalar and the point from the oracle (zkp/groth16/test.py:303-325 is this identity)."""
+    from zkhip.synthetic import random_scalars
+    rng = np.random.default_rng(7000 + n % 1000)
+    S, K = random_scalars(rng, n), random_scalars(rng, n)
+    S[0] = 0
+    S[1] = limb_row(o.R - 1)
+    Pts = _g2_bases(K)
+    want = co.g2_mul(o.G2, co.fr_dot_arr(S, K))
+    assert co.g2_from_arr(msm_g2(S, Pts))[0] == want
+    if n == (1 << 18) + 77:
+        # in full against the oracle's serial bucket method as well (a different restatement: unsigned windows, Jacobian)
+        assert np.array_equal(msm_g2(S, Pts), co.g2_msm_bucket_arr(S, Pts, 14))
+
+
+@pytest.mark.parametrize("pattern", ["witness_like", "all_equal", "forty_values"])
+def test_g2_msm_skewed_scalars_large(pattern):
+    """The G2 twin of test_g1_msm_skewed_scalars_large: hot digits at 2^18 points with 16-bit windows -- what a Groth16
+    B query sees from a boolean-heavy witness (msm_heavy_kernel<Fp2>, the multi-workgroup cell sort) -- bit-exact against
+    the oracle's serial bucket MSM, blocking and with three submissions in flight."""
+    import torch
+    from zkhip.synthetic import random_scalars
+    rng = np.random.default_rng(4343)
+    n = (1 << 18) + 77
+    K = random_scalars(rng, n)
+    Pts = _g2_bases(K)
+    S = random_scalars(rng, n)
+    pick = rng.random(n)
+    if pattern == "witness_like":
+        S[pick < 0.25] = 0
+        S[(pick >= 0.25) & (pick < 0.5)] = limb_row(1)
+    elif pattern == "all_equal":
+        S[:] = S[0]
+    else:
+        S = S[rng.integers(0, 40, size=n)]
+    want = co.g2_msm_bucket_arr(S, Pts, 14)
+    assert co.g2_from_arr(want)[0] == co.g2_mul(o.G2, co.fr_dot_arr(S, K))       # the oracle against its own closed form
+    assert np.array_equal(msm_g2(S, Pts), want)
+    dS, dP = torch.from_numpy(S.view(np.int64)).cuda(), torch.from_numpy(Pts.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    plan = MsmPlan(_lib.GROUP_G2, n)
+    tickets = [plan.submit(dS.data_ptr(), dP.data_ptr(), n, st) for _ in range(plan.max_in_flight())]
+    for t in tickets:
+        assert np.array_equal(plan.collect_limbs(t)[0], want)
+    # bound bases (what the at-scale prover runs) must give the same point
+    plan.bind(dP.data_ptr(), n, st)
+    assert np.array_equal(plan.run_limbs(dS.data_ptr(), None, n, st)[0], want)
+    plan.close()
+
+
 def test_device_plan_reuse_partials_and_profile():
     import torch
     rng = np.random.default_rng(12)

@@ -434,3 +434,28 @@ def test_c_oracle_bucket_msm_matches_naive():
     assert (co.g1_msm_bucket_arr(S[:0], P[:0], 8) == 0).all()
     for threads in (1, 3, 64):
         assert (co.g1_msm_bucket_mt_arr(S, P, 7, threads) == want).all()   # windows spread over threads
+
+
+def test_c_oracle_g2_bucket_msm_matches_naive():
+    """orc_g2_msm_bucket (serial Pippenger in G2) == orc_g2_msm (per-term double-and-add), several window widths; the G2
+    fixed-base batch is the per-scalar orc_g2_mul."""
+    rng = np.random.default_rng(78)
+    n = 120
+    sc = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, o.R - 1, 1
+    ks = [int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)]
+    P = co.g2_fixed_base_arr(o.G2, co.to_limbs(ks))
+    assert co.g2_from_arr(P[3])[0] == co.g2_mul(o.G2, ks[3])
+    P[5] = 0                      # infinity input
+    P[7] = P[6]                   # duplicate point
+    S = co.to_limbs(sc)
+    want = co.g2_msm_arr(S, P)
+    for c in (1, 5, 13):
+        assert (co.g2_msm_bucket_arr(S, P, c) == want).all()
+    assert (co.g2_msm_bucket_arr(S[:0], P[:0], 8) == 0).all()
+    # closed form: P_i = k_i G2  =>  MSM = (sum s_i k_i) G2
+    sc2 = list(sc)
+    ks2 = list(ks)
+    ks2[5] = 0
+    ks2[7] = ks2[6]
+    assert co.g2_from_arr(want)[0] == co.g2_mul(o.G2, sum(a * b for a, b in zip(sc2, ks2)) % o.R)
