@@ -8,6 +8,12 @@
 #pragma once
 #include "field.h"
 
+// true when the condition holds in ANY lane of the wavefront (a wave-uniform value: branching on it is a scalar branch)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#else
+#define ZK_WAVE_ANY(c) (c)
+#endif
 namespace zk {
 
 template <class F> struct Affine {
@@ -99,15 +105,26 @@ template <class F> ZK_HD void xyzz_add_affine(Xyzz<F> &acc, const Affine<F> &q) 
 // instead of three, Q - X3 is only normalised.  q.y may be a negated table entry (fe_neg_once<2> of F_p^2: normalised, <= 2p).
 ZK_HD void xyzz_add_affine(Xyzz<Fp2> &acc, const Affine<Fp2> &q) {
     if (q.is_inf()) return;
-    if (acc.is_inf()) {
-        acc = Xyzz<Fp2>{q.x, q.y, Fp2::one(), Fp2::one()};
-        return;
-    }
     const Fp2 p = fp2_mul_minus_lazy<4>(q.x, acc.zz, acc.x);    // < 6.06p
     const Fp2 r = fp2_mul_minus_lazy<2>(q.y, acc.zzz, acc.y);   // < 4.06p
-    if (p.is_zero()) {
-        if (r.is_zero())
-            acc = xyzz_dbl_affine(q);
+    // The exceptional cases are classified HERE, completely, before the main path starts: under SIMT both sides of a divergent
+    // branch are laid out one after the other, and whatever the later side needs stays in registers across the earlier one -- with
+    // `if (p.is_zero()) { ... dbl(q) ... }` written the usual way that was q (36 registers) and the limbs of p and r for the full
+    // zero tests (the kernel spilled).  The full tests sit behind a wave-uniform branch (almost never taken), the doubling works
+    // on acc itself (acc == q as points), and only acc == infinity still reads q.
+    int special = 0;   // 1: acc is infinity, 2: acc == q, 3: acc == -q
+    const bool c_inf = acc.zz.maybe_zero(), c_p = p.maybe_zero();
+    if (ZK_WAVE_ANY(c_inf || c_p)) {
+        if (c_inf && acc.is_inf())
+            special = 1;
+        else if (c_p && p.is_zero())
+            special = r.is_zero() ? 2 : 3;
+    }
+    if (special) {
+        if (special == 1)
+            acc = Xyzz<Fp2>{q.x, q.y, Fp2::one(), Fp2::one()};
+        else if (special == 2)
+            acc = xyzz_dbl(acc);
         else
             acc = Xyzz<Fp2>::inf();
         return;
@@ -126,35 +143,51 @@ ZK_HD void xyzz_add_affine(Xyzz<Fp2> &acc, const Affine<Fp2> &q) {
     acc.zzz = fe_mul(acc.zzz, ppp);
 }
 
-// acc += q (add-2008-s), all exceptional cases handled.
+// acc += q (add-2008-s), all exceptional cases handled -- and classified before the main path, as in the G2 mixed addition above:
+// an infinite operand is settled first (acc = q is a handful of moves), the products are formed for every lane, and acc == +-q is
+// recognised from P = U2 - U1, R = S2 - S1 behind a wave-uniform branch; the doubling works on acc, so nothing of q outlives the
+// main path's own use of it.
 template <class F> ZK_HD void xyzz_add(Xyzz<F> &acc, const Xyzz<F> &q) {
-    if (q.is_inf()) return;
-    if (acc.is_inf()) {
-        acc = q;
-        return;
+    int special = 0;   // 1: nothing (left) to add, 2: acc == q, 3: acc == -q
+    const bool c_q = q.zz.maybe_zero(), c_a = acc.zz.maybe_zero();
+    if (ZK_WAVE_ANY(c_q || c_a)) {
+        if (c_q && q.is_inf()) {
+            special = 1;
+        } else if (c_a && acc.is_inf()) {
+            acc = q;
+            special = 1;
+        }
     }
-    F u1 = fe_mul(acc.x, q.zz);              // 8*2
-    F u2 = fe_mul(q.x, acc.zz);
-    F s1 = fe_mul(acc.y, q.zzz);
-    F s2 = fe_mul(q.y, acc.zzz);
-    F p = fe_sub<2>(u2, u1);                 // < 4m
-    F r = fe_sub<2>(s2, s1);                 // < 4m
-    if (p.is_zero()) {
-        if (r.is_zero())
-            acc = xyzz_dbl(acc);
-        else
+    // (U1, S1, T1, T2) = (X1 ZZ2, Y1 ZZZ2, ZZ1 ZZ2, ZZZ1 ZZZ2) is acc itself in other coordinates (x = U1 / T1, y = S1 / T2,
+    // T1^3 = T2^2), so after these six products neither acc nor q is needed any more -- 108 live registers in G2 instead of 144
+    // (the two ZZ pairs), which is what lets the reduction kernels keep two wavefronts per SIMD.
+    const F u1 = fe_mul(acc.x, q.zz);        // 8*2
+    const F u2 = fe_mul(q.x, acc.zz);
+    const F t1 = fe_mul(acc.zz, q.zz);
+    const F s1 = fe_mul(acc.y, q.zzz);
+    const F s2 = fe_mul(q.y, acc.zzz);
+    const F t2 = fe_mul(acc.zzz, q.zzz);
+    const F p = fe_sub<2>(u2, u1);           // < 4m
+    const F r = fe_sub<2>(s2, s1);           // < 4m
+    const bool c_p = !special && p.maybe_zero();
+    if (ZK_WAVE_ANY(c_p)) {
+        if (c_p && p.is_zero()) special = r.is_zero() ? 2 : 3;
+    }
+    if (special) {
+        if (special == 2)
+            acc = xyzz_dbl(Xyzz<F>{u1, s1, t1, t2});
+        else if (special == 3)
             acc = Xyzz<F>::inf();
         return;
     }
-    F pp = fe_sqr(p);
-    F ppp = fe_mul(p, pp);
-    F qq = fe_mul(u1, pp);
-    F x3 = fe_sub2<6>(fe_sqr(r), ppp, qq);                           // < 8m
-    F y3 = fe_mulsub<2>(r, fe_sub_once<8>(qq, x3), s1, ppp);         // 4*11 + 3*2 < 169;  < 2m
+    const F pp = fe_sqr(p);
+    const F ppp = fe_mul(p, pp);
+    const F qq = fe_mul(u1, pp);
+    acc.zz = fe_mul(t1, pp);
+    acc.zzz = fe_mul(t2, ppp);
+    const F x3 = fe_sub2<6>(fe_sqr(r), ppp, qq);                     // < 8m
+    acc.y = fe_mulsub<2>(r, fe_sub_once<8>(qq, x3), s1, ppp);        // 4*11 + 3*2 < 169;  < 2m
     acc.x = x3;
-    acc.y = y3;
-    acc.zz = fe_mul(fe_mul(acc.zz, q.zz), pp);
-    acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), ppp);
 }
 
 // Affine x = X/ZZ, y = Y/ZZZ with one inversion: since ZZ^3 = ZZZ^2, 1/ZZ = (ZZ/ZZZ)^2.

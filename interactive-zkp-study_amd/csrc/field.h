@@ -124,6 +124,7 @@ template <class Tag> struct alignas(4) Fe {
         return o == 0;
     }
     ZK_HD bool is_zero() const;              // value == 0 mod m (any lazy representative)
+    ZK_HD bool maybe_zero() const;           // false: certainly non-zero (is_zero's three-instruction reject); true: run is_zero()
     ZK_HD bool equals(const Fe &b) const;    // values equal mod m
 };
 
@@ -188,6 +189,7 @@ template <class Tag> ZK_HD bool Fe<Tag>::is_zero() const {
     if ((((0u - l[0]) * C::inv) & LMASK) >= 16u) return false;
     return fe_reduce_full(*this).raw_is_zero();
 }
+template <class Tag> ZK_HD bool Fe<Tag>::maybe_zero() const { return (((0u - l[0]) * C::inv) & LMASK) < 16u; }
 template <class Tag> ZK_HD bool Fe<Tag>::equals(const Fe &b) const {
     const Fe x = fe_reduce_full(*this), y = fe_reduce_full(b);
     uint32_t o = 0;
@@ -647,6 +649,7 @@ struct Fp2 {
     static ZK_HD Fp2 zero() { return Fp2{Fp::zero(), Fp::zero()}; }
     static ZK_HD Fp2 one() { return Fp2{Fp::one(), Fp::zero()}; }
     ZK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    ZK_HD bool maybe_zero() const { return c0.maybe_zero() && c1.maybe_zero(); }
     ZK_HD bool equals(const Fp2 &b) const { return c0.equals(b.c0) && c1.equals(b.c1); }
 };
 

@@ -45,6 +45,7 @@ template <class Tag> struct HFe {
         return (uint64_t)0 - inv;
     }
     bool is_zero() const { return (l[0] | l[1] | l[2] | l[3]) == 0; }
+    bool maybe_zero() const { return is_zero(); }   // curve.h's cheap pre-test; host elements are canonical, so it is exact here
     bool equals(const HFe &b) const { return !memcmp(l, b.l, 32); }
     // Device element (9x29 limbs, lazy, Montgomery radix 2^261) <-> host element (radix 2^256).
     static HFe from_dev(const Fe<Tag> &a) {
@@ -181,6 +182,7 @@ struct HFp2 {
     static HFp2 zero() { return HFp2{HFp::zero(), HFp::zero()}; }
     static HFp2 one() { return HFp2{HFp::one(), HFp::zero()}; }
     bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    bool maybe_zero() const { return is_zero(); }
     bool equals(const HFp2 &b) const { return c0.equals(b.c0) && c1.equals(b.c1); }
     static HFp2 from_dev(const Fp2 &a) { return HFp2{HFp::from_dev(a.c0), HFp::from_dev(a.c1)}; }
     Fp2 to_dev() const { return Fp2{c0.to_dev(), c1.to_dev()}; }

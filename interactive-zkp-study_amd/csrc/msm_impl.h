@@ -721,7 +721,7 @@ __device__ __forceinline__ void reduce_task(Xyzz<F> *base, uint32_t s, uint32_t 
     base[dst] = a;
 }
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 2 : 1)) void msm_reduce_wave_kernel(Xyzz<F> *x, uint32_t BL) {
+__global__ __launch_bounds__(64, 2) void msm_reduce_wave_kernel(Xyzz<F> *x, uint32_t BL) {
     Xyzz<F> *blk = x + ((size_t)blockIdx.x << BL);
     const uint32_t lane = threadIdx.x, m = BL - 6;
     Xyzz<F> *mine = blk + ((size_t)lane << m);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--n", type=int, default=0, help="points (default 2^log_n)")
     ap.add_argument("--bits", type=int, default=0, help="keep only the low BITS bits of every scalar (0 = uniform below r)")
+    ap.add_argument("--witness-like", action="store_true", help="a quarter of the scalars 0, a quarter 1, the rest uniform (SURVEY.md section 8 row D2)")
     ap.add_argument("--lib", default="", help="another build of libzkhip.so (same-session A/B runs; default: the in-tree library)")
     args = ap.parse_args()
     import time
@@ -45,6 +46,10 @@ def main():
         for wd in range(4):
             keep = min(64, max(0, args.bits - 64 * wd))
             scalars[:, wd] &= np.uint64((1 << keep) - 1)
+    if args.witness_like:
+        pick = rng.random(n)
+        scalars[pick < 0.25] = 0
+        scalars[(pick >= 0.25) & (pick < 0.5)] = np.array([1, 0, 0, 0], dtype=np.uint64)
     if args.group == "g1":
         gen = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
         points = np.zeros((n, 8), dtype=np.uint64)
