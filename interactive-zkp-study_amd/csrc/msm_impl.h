@@ -10,8 +10,8 @@
 //                workgroup per cell, single pass through LDS; cells beyond 10240 entries go to the multi-workgroup count /
 //                scatter pair) -> scan + rank (buckets by list length).
 //   accumulate   one thread per bucket, one wavefront per workgroup, lists of equal length side by side; XYZZ mixed
-//                additions (8M+2S).  Lists longer than heavy_th go to the heavy-bucket kernel (wavefront tasks of 64
-//                segments, __shfl trees, per-bucket last-arriver combine).
+//                additions (8M+2S).  Lists longer than heavy_th are summed by the first workgroups of the same grid (wavefront
+//                tasks of 64 segments, __shfl trees, per-bucket last-arriver combine), beside the ordinary lists.
 //   reduce       sum_j (j+1)*B_j per window without any serial running sum, in place: pair levels plus plain-sum trees
 //                over the odd entries of every level (sum_j j*B_j = sum_l 2^l * O_l).
 //   fold (host)  the W*c window/level sums are read back and combined by one 254-doubling Horner pass on the host
@@ -122,6 +122,7 @@ constexpr int CS_EPT = 20;       //   entries per thread (five 16-byte loads),
 constexpr int CS_MAX = CS_NT * CS_EPT;   // and the largest cell it takes (10240 entries; uniform 2^20-point MSMs have 8192 +- 90 per cell)
 constexpr int HEAVY_SEG = 32;    // entries per heavy-bucket segment (one thread each)
 constexpr int HEAVY_WAVE = 64 * HEAVY_SEG;  // entries per wavefront task
+constexpr uint32_t HEAVY_BLOCKS = 1024;     // workgroups at the head of the accumulate grid that take the heavy-bucket tasks
 
 struct SortBufs {
     uint32_t *counts;       // [W*nb]   list length of every bucket
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(SEG_NT) void msm_segscatter_kernel(SortBufs B, uint
 
 // grid covers the flattened bucket array, 2 buckets per thread: ranks the buckets by list length
 // (workgroup-local LDS histogram, one global reservation per non-empty length bin) and registers
-// heavy buckets together with their wavefront tasks (summed by msm_heavy_kernel).
+// heavy buckets together with their wavefront tasks (summed by the heavy workgroups of msm_accumulate_kernel).
 template <int DUMMY>
 __global__ __launch_bounds__(1024) void msm_rank_kernel(SortBufs B, uint32_t nbuckets) {
     __shared__ uint32_t hist[SIZE_BINS];
@@ -613,21 +614,6 @@ __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ 
     return acc;
 }
 
-template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
-                                                             const uint32_t *__restrict__ counts,
-                                                             const uint32_t *__restrict__ bucket_off,
-                                                             const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
-                                                             uint32_t nbuckets, uint32_t heavy_th) {
-    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= nbuckets) return;
-    const uint32_t b = perm[r];
-    const uint32_t len = counts[b];
-    if (len > heavy_th) return;  // summed by the heavy kernels
-    buckets[b] = sum_list(pts, sorted + bucket_off[b], len);
-}
-// [accumulate-kernel-end]
-
 template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
     Xyzz<F> r;
     constexpr int NW = sizeof(Xyzz<F>) / 4;
@@ -637,19 +623,21 @@ template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<
     for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
     return r;
 }
-// Heavy buckets (lists longer than heavy_th: skewed / witness-like scalars), ONE launch of one-wavefront workgroups; msm_rank_kernel has
-// written the task list.  A task = 64 consecutive HEAVY_SEG-entry segments of one bucket's list: every lane sums its segment, a __shfl
+// Heavy buckets (lists longer than heavy_th: skewed / witness-like scalars): wavefront tasks listed by msm_rank_kernel and taken by the
+// first HEAVY_BLOCKS workgroups of the accumulate grid (round 4; a kernel of its own behind the accumulate kernel before -- its ~46
+// dependent additions then sat on the critical path of a blocking MSM: 0.3 ms in G1, 1 ms in G2 with a quarter of the scalars equal
+// to one).  A task = 64 consecutive HEAVY_SEG-entry segments of one bucket's list: every lane sums its segment, a __shfl
 // tree leaves the task's partial sum in lane 0, which stores it and counts the task as finished on its bucket; the wavefront that
 // finishes a bucket's LAST task then sums that bucket's partials (stride-64 serial sums, __shfl tree) into the bucket array.  With
-// uniform scalars there are no tasks and every workgroup returns at once -- one nearly empty launch on the lane's stream where there
-// used to be three (expand, segments, combine), each of which waited its turn behind the neighbouring lanes' accumulate kernels.
+// uniform scalars there are no tasks and those workgroups return at once.
 // Hand-off of the partials between wavefronts: plain stores, s_waitcnt, agent-scope release, relaxed agent-scope counter; the last
-// arriver acquires at agent scope before it loads (MI355X_MICROARCH.md, inter-workgroup visibility).
+// arriver acquires at agent scope before it loads (MI355X_MICROARCH.md, inter-workgroup visibility).  Nothing ever waits for another
+// wavefront, so the order in which the hardware places the workgroups cannot deadlock it.
 template <class F>
-__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_heavy_kernel(const PackedAffine<F> *__restrict__ pts, SortBufs B, Xyzz<F> *partial,
-                                                                                   Xyzz<F> *__restrict__ buckets) {
+__device__ __forceinline__ void heavy_tasks(const PackedAffine<F> *__restrict__ pts, const SortBufs &B, Xyzz<F> *partial, Xyzz<F> *__restrict__ buckets,
+                                            uint32_t first, uint32_t stride) {
     const uint32_t ntasks = min(B.heavy_ctr[0], B.heavy_cap), lane = threadIdx.x;
-    for (uint32_t wt = blockIdx.x; wt < ntasks; wt += gridDim.x) {
+    for (uint32_t wt = first; wt < ntasks; wt += stride) {
         const uint2 task = B.heavy_tasks[wt];
         const uint4 hb = B.heavy_buckets[task.x];   // (bucket id, first task, tasks, -)
         const uint32_t len = B.counts[hb.x], lo = (task.y * 64 + lane) * HEAVY_SEG;
@@ -683,6 +671,34 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 3 : 2)) void msm_heavy_k
         }
         if (lane == 0) buckets[hb.x] = acc;
     }
+}
+
+template <class F>
+__global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumulate_kernel(const PackedAffine<F> *__restrict__ pts, const uint32_t *__restrict__ sorted,
+                                                             const uint32_t *__restrict__ counts,
+                                                             const uint32_t *__restrict__ bucket_off,
+                                                             const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
+                                                             uint32_t nbuckets, uint32_t heavy_th, SortBufs B, Xyzz<F> *partial, uint32_t heavy_blocks) {
+    if (blockIdx.x < heavy_blocks) {
+        heavy_tasks(pts, B, partial, buckets, blockIdx.x, heavy_blocks);
+        return;
+    }
+    const uint32_t r = (blockIdx.x - heavy_blocks) * 64 + threadIdx.x;
+    if (r >= nbuckets) return;
+    const uint32_t b = perm[r];
+    const uint32_t len = counts[b];
+    if (len > heavy_th) return;  // summed by the heavy blocks
+    buckets[b] = sum_list(pts, sorted + bucket_off[b], len);
+}
+// [accumulate-kernel-end]
+
+// A grid of workgroups that do nothing, launched between the accumulate kernel and the bucket reduction.  Measured, not understood
+// (profiles/r04_experiments.md): with the reduction's first kernel directly behind the accumulate kernel that kernel takes 25 % longer
+// (G1 0.28 instead of 0.22 ms, G2 0.87 instead of 0.70 ms for 2^20 points, blocking and in every A/B pair); a 1024-workgroup no-op
+// between the two restores it, a one-workgroup no-op does not, and an LDS reservation that pins the reduction to one wavefront per
+// SIMD does not either.  Until round 4 the (normally empty) heavy-bucket kernel sat there and did this by accident.
+template <int DUMMY> __global__ void msm_boundary_kernel(const uint32_t *p) {
+    if (p == nullptr && threadIdx.x == 999) __builtin_trap();   // never taken (p is the lane's error counter): keeps the body from being empty
 }
 
 // ------------------------------------------------------------------------------ reduce
@@ -1026,14 +1042,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(L, 2);
         const uint32_t nbuckets = W * nb;
         mark(L, 5);
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((nbuckets + 63) / 64), dim3(64), 0, st, L.pts_m.template as<PackedAffine<F>>(),
+        // Heavy buckets (lists beyond heavy_th: skewed / witness-like scalars; normally none) are summed by the FIRST heavy_blocks
+        // workgroups of the same grid -- wavefront tasks msm_rank_kernel has listed -- so their long dependent chains start first and
+        // run beside the ordinary lists instead of after them; with no task listed those workgroups return at once.
+        const uint32_t heavy_blocks = std::min<uint32_t>(heavy_cap, HEAVY_BLOCKS);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3(heavy_blocks + (nbuckets + 63) / 64), dim3(64), 0, st, L.pts_m.template as<PackedAffine<F>>(),
                            L.sorted.template as<uint32_t>(), L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(),
-                           L.perm.template as<uint32_t>(), L.arena.template as<Xyzz<F>>(), nbuckets, B.heavy_th);
+                           L.perm.template as<uint32_t>(), L.arena.template as<Xyzz<F>>(), nbuckets, B.heavy_th, B,
+                           L.heavy_partial.template as<Xyzz<F>>(), heavy_blocks);
         mark(L, 6);
-        // heavy buckets (normally none): one launch whose workgroups return at once when msm_rank_kernel registered no task.  Same stream:
-        // a lane's low-occupancy phases are filled by the neighbouring lanes, and the device only has a few hardware queues.
-        hipLaunchKernelGGL((msm_heavy_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 4)), dim3(64), 0, st, L.pts_m.template as<PackedAffine<F>>(), B,
-                           L.heavy_partial.template as<Xyzz<F>>(), L.arena.template as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_boundary_kernel<0>), dim3(1024), dim3(64), 0, L.stream, err_dev(L));
     }
 
     // Enqueues the whole GPU pipeline plus the 36 KiB read-back; returns a ticket.  The work runs on the lane's own
@@ -1113,12 +1131,12 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         hipLaunchKernelGGL((msm_rank_kernel<0>), dim3((FIX_NB + 2047) / 2048), dim3(1024), 0, ls, B, FIX_NB);
         mark(L, 2);
         mark(L, 5);
-        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3((FIX_NB + 63) / 64), dim3(64), 0, ls, table, L.sorted.template as<uint32_t>(),
+        const uint32_t heavy_blocks = std::min<uint32_t>(heavy_cap, HEAVY_BLOCKS);
+        hipLaunchKernelGGL((msm_accumulate_kernel<F>), dim3(heavy_blocks + (FIX_NB + 63) / 64), dim3(64), 0, ls, table, L.sorted.template as<uint32_t>(),
                            L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(), L.perm.template as<uint32_t>(),
-                           L.arena.template as<Xyzz<F>>(), FIX_NB, B.heavy_th);
+                           L.arena.template as<Xyzz<F>>(), FIX_NB, B.heavy_th, B, L.heavy_partial.template as<Xyzz<F>>(), heavy_blocks);
         mark(L, 6);
-        hipLaunchKernelGGL((msm_heavy_kernel<F>), dim3(std::min<uint32_t>(heavy_cap, 256 * 4)), dim3(64), 0, ls, table, B, L.heavy_partial.template as<Xyzz<F>>(),
-                           L.arena.template as<Xyzz<F>>());
+        hipLaunchKernelGGL((msm_boundary_kernel<0>), dim3(1024), dim3(64), 0, L.stream, err_dev(L));
         mark(L, 3);
         const uint32_t levels = FIX_C - 1, BL = 9;
         hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3(FIX_NB >> BL), dim3(64), 0, ls, L.arena.template as<Xyzz<F>>(), BL);

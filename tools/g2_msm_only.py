@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
 import torch
 from zkhip import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = sys.argv[1]          # another build of libzkhip.so (same-session A/B traces)
 from zkhip.device import MsmPlan
 from zkhip.field import G2, g2_to_limbs
 from zkhip.synthetic import random_scalars
