@@ -77,6 +77,33 @@ def oracle_g1_mul(k):
     return c_oracle.g1_mul(py_ref.G1, int(k) % R_MOD)
 
 
+def oracle_g2_mul(k):
+    """k * G2 as ((x0, x1), (y0, y1)) | None from the C oracle (checker only, like oracle_g1_mul)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    import py_ref
+    return c_oracle.g2_mul(py_ref.G2, int(k) % R_MOD)
+
+
+def g2_point_ints(pt):
+    return None if pt is None else tuple(tuple(int(c) for c in v.coeffs) for v in pt)
+
+
+def blocking_ms(plan, d_s, d_p, n, stream, reps=10):
+    """One MSM on the GPU at a time: submit, wait for the result, submit the next -- what a single commitment or proof element costs a
+    caller that needs the point before it can go on (a Fiat-Shamir round); min and mean over `reps` calls after two untimed ones."""
+    import torch
+    for _ in range(2):
+        res = plan.run(d_s, d_p, n, stream)
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = plan.run(d_s, d_p, n, stream)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return res, round(min(ts), 4), round(sum(ts) / len(ts), 4)
+
+
 def point_ints(pt):
     """A facade G1 point (FQ, FQ) | None as plain integers, the oracle's format."""
     return None if pt is None else (int(pt[0]), int(pt[1]))
@@ -101,8 +128,8 @@ def committed_issue_rate(kernel):
         tagged = json.load(open(meta)).get("arithmetic_source_sha256")
     except (OSError, ValueError):
         tagged = None
-    if tagged is not None and tagged != arithmetic_source_hash():
-        return None                                 # the counter pass was taken from other arithmetic sources: do not quote it
+    if tagged != arithmetic_source_hash():
+        return None                                 # taken from other arithmetic sources, or not tagged at all: do not quote it
     for r in csv.DictReader(open(found[-1])):
         if r["kernel"] == kernel:
             v = float(r["valu_insts_per_simd_cycle"])
@@ -229,6 +256,7 @@ def main():
     ap.add_argument("--plonk-log-n", type=int, default=20, help="log2 gates of the secondary device-resident PLONK prove() timing (0 = skip)")
     ap.add_argument("--no-bound", action="store_true", help="skip the secondary bound-bases run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--no-facade", action="store_true", help="skip the secondary toy-size facade proofs (their small MSMs would enter a profiler's per-kernel averages)")
+    ap.add_argument("--no-g2", action="store_true", help="skip the secondary G2 measurements")
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--shard-total-log", type=int, default=26, help="N > 1 only: log2 points of the secondary ONE-MSM-sharded-over-all-GPUs "
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
@@ -474,7 +502,54 @@ def main():
         bms = (time.perf_counter() - tb0) / bsteps * 1e3
         extra["bound_bases"] = {"ms_per_step": round(bms, 4), "points_per_s": n / (bms * 1e-3), "bind_ms": round(bind_s * 1e3, 1),
                                 "table_bytes": 13 * n * 64, "same_result_as_unbound": bool(np.array_equal(bres[0], result[0]) and bres[1] == result[1])}
+        # the same two modes as BLOCKING calls (one MSM on the chip at a time): the figure a prover's serial rounds see
+        _, b_min, b_mean = blocking_ms(plan, d_scalars.data_ptr(), None, n, stream)
         plan.bind(None, 0, stream)
+        ures, u_min, u_mean = blocking_ms(plan, d_scalars.data_ptr(), d_points.data_ptr(), n, stream)
+        extra["blocking"] = {"what": "uniform 2^%d-point G1 MSM, one call at a time (submit -> result), min / mean of 10" % args.log_n,
+                             "unbound_ms_per_msm_blocking": u_min, "unbound_mean_ms": u_mean,
+                             "bound_ms_per_msm_blocking": b_min, "bound_mean_ms": b_mean,
+                             "verified_closed_form": bool(point_ints(ures) == oracle_g1_mul(local_dot))}
+
+    # ---- secondary: G2 (proof_b's query, zkp/groth16/proving.py:35-45): 2^20 points P_i = k_i * G2, blocking calls --
+    # uniform scalars with unbound and bound bases, and witness-like scalars (a quarter 0, a quarter 1) -- each against the oracle's
+    # closed form (sum s_i k_i) * G2
+    if rank == 0 and world == 1 and n > (1 << 17) and not args.no_g2:
+        try:
+            from zkhip.field import G2 as G2_GEN, g2_to_limbs
+            p2 = np.zeros((n, 16), dtype=np.uint64)
+            _lib.check(lib.zk_fixed_base_g2(_lib.ptr(g2_to_limbs([G2_GEN])), _lib.ptr(ks), n, _lib.ptr(p2)))
+            d_p2 = torch.from_numpy(p2.view(np.int64)).to(dev)
+            del p2
+            plan2 = MsmPlan(_lib.GROUP_G2, n)
+            plan2.set_profiling(True)
+            want = oracle_g2_mul(local_dot)
+            g2res, g_min, g_mean = blocking_ms(plan2, d_scalars.data_ptr(), d_p2.data_ptr(), n, stream, 6)
+            g2 = {"unbound": {"ms_per_msm_blocking": g_min, "mean_ms": g_mean, "stage_ms": [round(v, 4) for v in plan2.stage_ms()],
+                              "verified_closed_form": bool(g2_point_ints(g2res) == want)}}
+            wl2 = scalars.copy()
+            pick2 = np.random.default_rng(0x5EEDB257).random(n)
+            wl2[pick2 < 0.25] = 0
+            wl2[(pick2 >= 0.25) & (pick2 < 0.5)] = np.array([1, 0, 0, 0], dtype=np.uint64)
+            d_wl2 = torch.from_numpy(wl2.view(np.int64)).to(dev)
+            want_wl = oracle_g2_mul(limbs_dot_mod_r(wl2, ks))
+            wres, w_min, w_mean = blocking_ms(plan2, d_wl2.data_ptr(), d_p2.data_ptr(), n, stream, 6)
+            g2["witness_like"] = {"ms_per_msm_blocking": w_min, "mean_ms": w_mean, "stage_ms": [round(v, 4) for v in plan2.stage_ms()],
+                                  "ratio_to_uniform": round(w_min / g_min, 3), "verified_closed_form": bool(g2_point_ints(wres) == want_wl)}
+            tb0 = time.perf_counter()
+            plan2.bind(d_p2.data_ptr(), n, stream)
+            bind2 = (time.perf_counter() - tb0) * 1e3
+            bres, gb_min, gb_mean = blocking_ms(plan2, d_scalars.data_ptr(), None, n, stream, 6)
+            g2["bound"] = {"ms_per_msm_blocking": gb_min, "mean_ms": gb_mean, "stage_ms": [round(v, 4) for v in plan2.stage_ms()],
+                           "bind_ms": round(bind2, 1), "verified_closed_form": bool(g2_point_ints(bres) == want)}
+            wbres, wb_min, wb_mean = blocking_ms(plan2, d_wl2.data_ptr(), None, n, stream, 6)
+            g2["bound_witness_like"] = {"ms_per_msm_blocking": wb_min, "mean_ms": wb_mean, "verified_closed_form": bool(g2_point_ints(wbres) == want_wl)}
+            extra["g2"] = g2
+            plan2.close()
+            del d_p2, d_wl2
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 -- a secondary measurement must not take the headline line down with it
+            extra["g2"] = {"error": repr(exc)}
 
     # ---- secondary: NTT forward + inverse round trip (BASELINE.json configs[2]).  With N > 1 every rank transforms a
     # polynomial of its own (batch-parallel mode: no exchange) between barriers; the aggregate is N transforms per span.
@@ -514,45 +589,49 @@ def main():
             agg = world * 2 * reps * m / span   # wall clock between barriers (includes launch latency), all ranks
             extra["ntt"]["all_gpus"] = {"mode": "one polynomial per GPU, no exchange", "elements_per_s": agg,
                                         "hbm_frac_per_gpu": 64.0 * agg / world / 1e9 / HBM_PEAK_GBS}
-        if rank == 0 and args.cpu_sample:
-            # CPU lines beside the NTT (row D4): the reference-shaped recursive fft (polynomial.py:292-341) in pure Python on prefixes
-            # of 2^8 .. 2^14 and 2^16 coefficients (n log n fit, extrapolated to the config sizes), and the C oracle's iterative NTT on
-            # the whole vector -- each compared with the GPU output
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import py_ref
-            import c_oracle
-            fit_n, fit_t, all_same = [], [], True
-            for Ls in [v for v in (8, 10, 12, 14, 16) if v <= L]:
-                ms_ = 1 << Ls
-                small = torch.from_numpy(coeffs[:ms_].copy().view(np.int64)).to(dev)
-                NttPlan(Ls).run(small.data_ptr(), False, None, stream)
+        if rank == 0 and world == 1 and args.cpu_sample:
+            # (one rank only: with N > 1 the other ranks would sit in their next collective through a pure-Python fft)
+            try:
+                # CPU lines beside the NTT (row D4): the reference-shaped recursive fft (polynomial.py:292-341) in pure Python on prefixes
+                # of 2^8 .. 2^14 and 2^16 coefficients (n log n fit, extrapolated to the config sizes), and the C oracle's iterative NTT on
+                # the whole vector -- each compared with the GPU output
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import py_ref
+                import c_oracle
+                fit_n, fit_t, all_same = [], [], True
+                for Ls in [v for v in (8, 10, 12, 14, 16) if v <= L] or [L]:
+                    ms_ = 1 << Ls
+                    small = torch.from_numpy(coeffs[:ms_].copy().view(np.int64)).to(dev)
+                    NttPlan(Ls).run(small.data_ptr(), False, None, stream)
+                    torch.cuda.synchronize()
+                    ints = _lib.limbs_to_ints(coeffs[:ms_])
+                    w_s = py_ref.get_root_of_unity(ms_)
+                    p0 = time.perf_counter()
+                    py_out = py_ref.fft(ints, w_s)
+                    pdt = time.perf_counter() - p0
+                    same_py = _lib.limbs_to_ints(small.cpu().numpy().view(np.uint64).reshape(-1, 4)) == [int(v) for v in py_out]
+                    all_same = all_same and same_py
+                    fit_n.append(ms_)
+                    fit_t.append(pdt)
+                nfit = fit_and_extrapolate(fit_n, fit_t, (22, 24), True)
+                nfit["every_sample_equals_gpu"] = bool(all_same)
+                nplan.run(d.data_ptr(), False, None, stream)
                 torch.cuda.synchronize()
-                ints = _lib.limbs_to_ints(coeffs[:ms_])
-                w_s = py_ref.get_root_of_unity(ms_)
-                p0 = time.perf_counter()
-                py_out = py_ref.fft(ints, w_s)
-                pdt = time.perf_counter() - p0
-                same_py = _lib.limbs_to_ints(small.cpu().numpy().view(np.uint64).reshape(-1, 4)) == [int(v) for v in py_out]
-                all_same = all_same and same_py
-                fit_n.append(ms_)
-                fit_t.append(pdt)
-            nfit = fit_and_extrapolate(fit_n, fit_t, (22, 24), True)
-            nfit["every_sample_equals_gpu"] = bool(all_same)
-            nplan.run(d.data_ptr(), False, None, stream)
-            torch.cuda.synchronize()
-            gpu_fwd = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
-            nplan.run(d.data_ptr(), True, None, stream)
-            c0_ = time.perf_counter()
-            c_out = c_oracle.ntt_arr(coeffs, py_ref.get_root_of_unity(m))
-            cdt_ = time.perf_counter() - c0_
-            extra["ntt"]["cpu_baseline"] = {
-                "value": ms_ / pdt, "unit": "elements/s", "cores": 1, "kind": "port",
-                "sample": "first 2^%d coefficients, oracle/py_ref.fft (recursive radix-2, as zkp/plonk/polynomial.py:292-341); %.2f s; "
-                          "equals the GPU transform of the same sample: %s" % (Ls, pdt, same_py),
-                "host": host_description(), "extrapolation": nfit,
-                "compiled_c": {"value": m / cdt_, "unit": "elements/s", "cores": 1, "kind": "port",
-                               "sample": "all 2^%d coefficients, oracle/bn254_oracle.c orc_ntt; %.2f s; bit-identical to the GPU forward transform: %s"
-                                         % (L, cdt_, bool(np.array_equal(gpu_fwd, c_out)))}}
+                gpu_fwd = d.cpu().numpy().view(np.uint64).reshape(-1, 4)
+                nplan.run(d.data_ptr(), True, None, stream)
+                c0_ = time.perf_counter()
+                c_out = c_oracle.ntt_arr(coeffs, py_ref.get_root_of_unity(m))
+                cdt_ = time.perf_counter() - c0_
+                extra["ntt"]["cpu_baseline"] = {
+                    "value": ms_ / pdt, "unit": "elements/s", "cores": 1, "kind": "port",
+                    "sample": "first 2^%d coefficients, oracle/py_ref.fft (recursive radix-2, as zkp/plonk/polynomial.py:292-341); %.2f s; "
+                              "equals the GPU transform of the same sample: %s" % (Ls, pdt, same_py),
+                    "host": host_description(), "extrapolation": nfit,
+                    "compiled_c": {"value": m / cdt_, "unit": "elements/s", "cores": 1, "kind": "port",
+                                   "sample": "all 2^%d coefficients, oracle/bn254_oracle.c orc_ntt; %.2f s; bit-identical to the GPU forward transform: %s"
+                                             % (L, cdt_, bool(np.array_equal(gpu_fwd, c_out)))}}
+            except Exception as exc:  # noqa: BLE001 -- a secondary CPU line must not take the headline line down with it
+                extra["ntt"]["cpu_baseline"] = {"error": repr(exc)}
         del d, ref
         # ONE transform of 2^24 points spread over the ranks (four-step, one all-to-all; zkhip.distributed.DistNtt)
         if dist_on and args.dist_ntt_log_n:
@@ -707,6 +786,15 @@ def main():
             extra["groth16_prove"] = bench_groth16.run(args.groth16_log_m, 6)
         except Exception as exc:  # the headline number must not depend on the secondary measurement
             extra["groth16_prove"] = {"error": repr(exc)}
+        # the same prover on a witness of the kind real circuits have: half of the wires are bits (they enter the merged proof_C query
+        # directly and fill a few buckets with hundreds of thousands of points: the heavy-bucket path)
+        try:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            extra["groth16_prove_bool_witness"] = bench_groth16.run(args.groth16_log_m, 4, circuit="bool")
+        except Exception as exc:  # noqa: BLE001
+            extra["groth16_prove_bool_witness"] = {"error": repr(exc)}
 
     # ---- secondary: the reference-signature facade at the reference's own sizes (BASELINE.json configs[0]: toy Groth16 / PLONK proofs
     # through the host-buffer ABI, one library call per primitive; the entry points keep their plans)

@@ -248,6 +248,12 @@ int zk_fr_eval_dev(zk_frvec *ws, const void *const *d_coefs /* k HOST-side array
  */
 int zk_fixed_base_g1(const uint64_t base_xy[8], const uint64_t *scalars, size_t n, uint64_t *out_points /* n*8 */);
 int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t n, uint64_t *out_points /* n*16 */);
+/* The same batch with the scalars and the points in DEVICE buffers (base_xy stays a HOST pointer): key generation at scale, where
+ * the exponents x^j, (beta A_i + alpha B_i + C_i)(x) / delta, x^k Z(x) / delta (setup.py:18-60) and tau^i (srs.py:68-85) are produced
+ * by the F_r vector kernels above and the points go straight into zk_msm_plan_bind_points.  Enqueued on `stream`, which is
+ * synchronised once before the call returns (the call owns its window table). */
+int zk_fixed_base_g1_dev(const uint64_t base_xy[8], const void *d_scalars, size_t n, void *d_out_points /* n*8 limbs */, void *stream);
+int zk_fixed_base_g2_dev(const uint64_t base_xy[16], const void *d_scalars, size_t n, void *d_out_points /* n*16 limbs */, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Single group operations on the device (HOST buffers; batch of n independent operations).

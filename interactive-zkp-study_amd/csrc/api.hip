@@ -168,6 +168,31 @@ template <class F> static int fixed_base_host(const uint64_t *base, const uint64
     return ZK_OK;
 }
 
+// The same batch on DEVICE buffers (at-scale setup: the scalars come out of F_r vector kernels and the points go straight into an MSM
+// plan's table, so neither visits the host).  Enqueued on `st`; the table is the call's own, hence one synchronisation of `st`
+// before it is released -- this is key generation, not the proving path.
+template <class F> static int fixed_base_dev(const uint64_t *base, const void *d_scalars, size_t n, void *d_out, hipStream_t st) {
+    constexpr size_t PB = 8 * F::CANON_WORDS;
+    if (n == 0) return ZK_OK;
+    if (n > 0xffffffffull) return invalid("zk_fixed_base_dev: n must fit 32 bits");
+    DevBuf dbase(PB);
+    ZK_HIP(hipMemcpyAsync(dbase.p, base, PB, hipMemcpyHostToDevice, st));
+    if (n < 4096) {
+        hipLaunchKernelGGL((group_op_kernel<F>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, 2, dbase.as<uint32_t>(), static_cast<const uint32_t *>(d_scalars),
+                           static_cast<uint32_t *>(d_out), (uint32_t)n);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));
+        return ZK_OK;
+    }
+    DevBuf table((size_t)FB_WINDOWS * FB_DIGITS * sizeof(Affine<F>));
+    hipLaunchKernelGGL((fixed_base_table_kernel<F>), dim3((FB_WINDOWS * FB_DIGITS + 63) / 64), dim3(64), 0, st, dbase.as<uint32_t>(), table.as<Affine<F>>());
+    hipLaunchKernelGGL((fixed_base_eval_kernel<F>), dim3((unsigned)((n + 64 * FB_PER_THREAD - 1) / (64 * FB_PER_THREAD))), dim3(64), 0, st, table.as<Affine<F>>(),
+                       static_cast<const uint32_t *>(d_scalars), static_cast<uint32_t *>(d_out), (uint32_t)n);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipStreamSynchronize(st));
+    return ZK_OK;
+}
+
 // Arithmetic-rate probes (zk_measure_rate): the integer-ALU ceilings the MSM kernels are priced against.
 // Every thread runs a dependent chain, the grid oversubscribes the chip, so the rate is the chip-wide
 // issue limit of the field multiplication / the mixed addition as compiled into this library.
@@ -551,6 +576,22 @@ int zk_fixed_base_g2(const uint64_t base_xy[16], const uint64_t *scalars, size_t
         int rc = require_device();
         if (rc) return rc;
         return fixed_base_host<Fp2>(base_xy, scalars, n, out_points);
+    });
+}
+int zk_fixed_base_g1_dev(const uint64_t base_xy[8], const void *d_scalars, size_t n, void *d_out_points, void *stream) {
+    return guarded([&] {
+        if (!base_xy || (n && (!d_scalars || !d_out_points))) return invalid("zk_fixed_base_g1_dev: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        return fixed_base_dev<Fp>(base_xy, d_scalars, n, d_out_points, static_cast<hipStream_t>(stream));
+    });
+}
+int zk_fixed_base_g2_dev(const uint64_t base_xy[16], const void *d_scalars, size_t n, void *d_out_points, void *stream) {
+    return guarded([&] {
+        if (!base_xy || (n && (!d_scalars || !d_out_points))) return invalid("zk_fixed_base_g2_dev: null pointer");
+        int rc = require_device();
+        if (rc) return rc;
+        return fixed_base_dev<Fp2>(base_xy, d_scalars, n, d_out_points, static_cast<hipStream_t>(stream));
     });
 }
 int zk_measure_rate(int what, double *out_per_sec) {

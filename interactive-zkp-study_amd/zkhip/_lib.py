@@ -79,6 +79,8 @@ _PROTOS = {
     "zk_fr_eval_dev": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_uint, _VP, _VP, _VP]),
     "zk_fixed_base_g1": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
     "zk_fixed_base_g2": (ctypes.c_int, [_VP, _VP, _SZ, _VP]),
+    "zk_fixed_base_g1_dev": (ctypes.c_int, [_VP, _VP, _SZ, _VP, _VP]),
+    "zk_fixed_base_g2_dev": (ctypes.c_int, [_VP, _VP, _SZ, _VP, _VP]),
     "zk_group_op": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _VP, _VP, _SZ, _VP]),
     "zk_measure_rate": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "zk_pairing": (ctypes.c_int, [_VP, _VP, _VP]),

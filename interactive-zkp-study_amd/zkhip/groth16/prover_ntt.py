@@ -15,8 +15,8 @@ at-scale one:
   * proof_A = alpha*G1 + MSM(u_A, sigma1_2) + r*delta*G1, and so on: one device MSM per query.
 
 Everything stays resident in HBM (torch tensors used as plain device buffers); correctness at any
-size is checked against closed-form scalars computed from the known toxic waste
-(zkp/groth16/test.py:303-325: proof_A == A*G1, proof_B == B*G2, proof_C == C*G1).
+size is checked by the tests and by bench.py against closed-form scalars the ORACLE computes from the known toxic waste
+(oracle/scale_ref.py; zkp/groth16/test.py:303-325: proof_A == A*G1, proof_B == B*G2, proof_C == C*G1).
 """
 import numpy as np
 
@@ -27,86 +27,7 @@ from ..field import CURVE_ORDER as R, G1, G2, fixed_base_mul, g1_to_limbs, g2_to
 COSET_SHIFT = 5  # the reference's coset generator (zkp/plonk/utils.py:166-167)
 
 
-def _batch_inverse(vals):
-    """Montgomery's trick on Python ints mod r."""
-    n = len(vals)
-    pref = [1] * (n + 1)
-    for i, v in enumerate(vals):
-        pref[i + 1] = pref[i] * v % R
-    inv = pow(pref[n], -1, R)
-    out = [0] * n
-    for i in range(n - 1, -1, -1):
-        out[i] = pref[i] * inv % R
-        inv = inv * vals[i] % R
-    return out
-
-
-class ChainCircuit:
-    """Synthetic R1CS with m = 2^log_m constraints t_{k+1} = t_k * t_k + t_k + c_k.
-
-    Wires: 0 = one, 1 + k = t_k (k = 0..m); public wires [0, 1] (the reference's default
-    pub_r_indexs).  Row k:  A = t_k,  B = t_k,  C = t_{k+1} - t_k - c_k * one  (<= 3 non-zeros)."""
-
-    def __init__(self, log_m, seed=1):
-        self.log_m = log_m
-        self.m = 1 << log_m
-        rng = np.random.default_rng(seed)
-        self.consts = [int(v) for v in rng.integers(1, 1 << 30, size=self.m)]
-        self.t0 = int(rng.integers(2, 1 << 62))
-        self.num_wires = self.m + 2
-        self.pub = [0, 1]
-
-    def witness(self):
-        """-> (w, a_evals, b_evals, c_evals): the wire values and the per-constraint products."""
-        t = [0] * (self.m + 1)
-        t[0] = self.t0
-        for k in range(self.m):
-            t[k + 1] = (t[k] * t[k] + t[k] + self.consts[k]) % R
-        w = [1] + t
-        a = t[:self.m]
-        c = [(t[k + 1] - t[k] - self.consts[k]) % R for k in range(self.m)]
-        return w, a, list(a), c
-
-    def r1cs_csr(self):
-        """The R1CS matrices in CSR form, {name: (row_ptr u32[m+1], col u32[nnz], vals (nnz, 4) u64 limbs)}:
-        row k:  A = B = e_{1+k};  C = e_{2+k} - e_{1+k} - c_k * e_0."""
-        m = self.m
-        k = np.arange(m, dtype=np.uint32)
-        one = np.zeros((m, 4), dtype=np.uint64)
-        one[:, 0] = 1
-        ab = (np.arange(m + 1, dtype=np.uint32), 1 + k, one)
-        col_c = np.stack([2 + k, 1 + k, np.zeros(m, dtype=np.uint32)], axis=1).reshape(-1)
-        minus_one = _lib.ints_to_limbs([R - 1])[0]
-        minus_c = _lib.ints_to_limbs([(-c) % R for c in self.consts])
-        vals_c = np.stack([one, np.tile(minus_one, (m, 1)), minus_c], axis=1).reshape(-1, 4)
-        return {"A": ab, "B": ab, "C": (3 * np.arange(m + 1, dtype=np.uint32), col_c.astype(np.uint32), vals_c)}
-
-    def lagrange_at(self, x):
-        """[L_k(x)] for the domain H = {w^k}: L_k(x) = (x^m - 1)/m * w^k / (x - w^k)."""
-        m = self.m
-        omega = pow(5, (R - 1) // m, R)
-        roots, cur = [], 1
-        for _ in range(m):
-            roots.append(cur)
-            cur = cur * omega % R
-        zx = (pow(x, m, R) - 1) % R
-        inv = _batch_inverse([(x - wk) % R for wk in roots])
-        scale = zx * pow(m, -1, R) % R
-        return [scale * roots[k] % R * inv[k] % R for k in range(m)], zx
-
-    def qap_at(self, x):
-        """Per-wire evaluations A_i(x), B_i(x), C_i(x) and Z(x) (lists of length num_wires)."""
-        L, zx = self.lagrange_at(x)
-        m, W = self.m, self.num_wires
-        A = [0] * W
-        C = [0] * W
-        for k in range(m):
-            A[1 + k] = L[k]
-        C[0] = (-sum(self.consts[k] * L[k] for k in range(m))) % R
-        for k in range(m):
-            C[1 + k] = (C[1 + k] - L[k]) % R
-            C[2 + k] = (C[2 + k] + L[k]) % R
-        return A, list(A), C, zx
+from .circuits import BoolChainCircuit, ChainCircuit  # noqa: F401  (the synthetic R1CS generators live in circuits.py)
 
 
 def _dev(arr):
@@ -114,48 +35,128 @@ def _dev(arr):
     return torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).cuda()
 
 
+SPLIT = 1024   # longest run of entries one thread of the sparse mat-vec walks (see _transposed_times)
+
+
+def _transposed_times(csr, num_wires, d_vec, stream):
+    """M^T v on the device for one R1CS matrix M (m x W, CSR on the host) and a device vector v of m elements: the per-wire sums
+    sum_k M[k][i] v[k].  The transpose is a stable sort of the entries by column (torch index work; the values keep their limb
+    form).  zk_fr_spmv_dev gives a row to ONE thread, and a wire such as `one` may sit in every constraint -- a row of 2^20 entries
+    took 0.7 s -- so rows are cut into runs of at most SPLIT entries (first product: one partial sum per run) which a second,
+    all-ones matrix adds up per wire (runs of one wire are consecutive; up to SPLIT^2 = 2^20 entries per wire in two levels)."""
+    import torch
+    from ..device import fr_spmv
+    row_ptr, col, vals = csr
+    m = row_ptr.shape[0] - 1
+    dev = d_vec.device
+    d_col = torch.from_numpy(col.astype(np.int64)).to(dev)
+    counts = torch.from_numpy(np.diff(row_ptr.astype(np.int64))).to(dev)
+    d_row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
+    order = torch.sort(d_col, stable=True).indices
+    lens = torch.bincount(d_col, minlength=num_wires)
+    if int(lens.max()) > SPLIT * SPLIT:
+        raise ValueError("a wire in more than %d constraints needs a third level here" % (SPLIT * SPLIT))
+    starts = torch.cumsum(lens, 0) - lens                                  # first entry of every wire
+    runs = (lens + SPLIT - 1) // SPLIT                                     # runs per wire (0 for a wire that appears nowhere)
+    run_first = torch.cumsum(runs, 0) - runs
+    n_runs = int(runs.sum())
+    wire_of_run = torch.repeat_interleave(torch.arange(num_wires, device=dev), runs)
+    ptr1 = torch.empty(n_runs + 1, dtype=torch.int64, device=dev)
+    ptr1[:n_runs] = starts[wire_of_run] + SPLIT * (torch.arange(n_runs, device=dev) - run_first[wire_of_run])
+    ptr1[n_runs] = d_col.shape[0]
+    ptr2 = torch.zeros(num_wires + 1, dtype=torch.int64, device=dev)
+    ptr2[1:] = torch.cumsum(runs, 0)
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    ptr1, col1, val1 = i32(ptr1), i32(d_row[order]), _dev(vals)[order].contiguous()
+    ptr2, col2 = i32(ptr2), i32(torch.arange(n_runs, device=dev))
+    val2 = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=dev).repeat(max(n_runs, 1), 1)
+    partial = torch.empty((max(n_runs, 1), 4), dtype=torch.int64, device=dev)
+    out = torch.empty((num_wires, 4), dtype=torch.int64, device=dev)
+    fr_spmv(ptr1.data_ptr(), col1.data_ptr(), val1.data_ptr(), d_vec.data_ptr(), partial.data_ptr(), n_runs, stream)
+    fr_spmv(ptr2.data_ptr(), col2.data_ptr(), val2.data_ptr(), partial.data_ptr(), out.data_ptr(), num_wires, stream)
+    return out
+
+
 class ScaleCRS:
-    """Device-resident CRS in the reference's sigma layout (zkp/groth16/setup.py:15-69)."""
+    """Device-resident CRS in the reference's sigma layout (zkp/groth16/setup.py:15-69), built ON the device.
+
+    The reference evaluates every wire polynomial at the toxic x with Python loops and multiplies G by each exponent in turn;
+    at 2^20 constraints that shape costs seconds of interpreter time around kernels that take milliseconds.  Here the exponents
+    are produced by the F_r vector kernels and never visit the host:
+        w^k                       zk_fr_scale_powers_dev on a vector of ones
+        1 / (x - w^k)             prefix and suffix product scans (zk_fr_scan_dev) and ONE host inversion of the total
+        L_k(x)                    (x^m - 1) / m * w^k / (x - w^k)
+        A_i(x), B_i(x), C_i(x)    the TRANSPOSED sparse R1CS matrices times L (zk_fr_spmv_dev)
+        L query exponents         (beta A_i + alpha B_i + C_i)(x) / delta       (zk_fr_lincomb_dev; zero at the public wires)
+        x^j, x^k Z(x) / delta     zk_fr_scale_powers_dev, zk_fr_lincomb_dev
+    and the points by the fixed-base batch kernels on device buffers (zk_fixed_base_g1_dev / _g2_dev)."""
 
     def __init__(self, circuit, alpha, beta, gamma, delta, x_val):
+        import torch
         self.circuit = circuit
         m, W = circuit.m, circuit.num_wires
-        self.toxic = dict(alpha=alpha % R, beta=beta % R, gamma=gamma % R, delta=delta % R, x=x_val % R)
-        Ax, Bx, Cx, zx = circuit.qap_at(x_val)
-        self.Ax, self.Bx, self.Cx, self.Zx = Ax, Bx, Cx, zx
-        dinv = pow(delta, -1, R)
-        powers, cur = [], 1
-        for _ in range(m):
-            powers.append(cur)
-            cur = cur * x_val % R
-        # sigma1_1 / sigma2_1 (setup.py:15-16, 62-63)
-        self.sigma1_1 = fixed_base_mul(G1, [alpha, beta, delta])
-        self.sigma2_1 = fixed_base_mul(G2, [beta, gamma, delta])
+        al, be, ga, de, x = (v % R for v in (alpha, beta, gamma, delta, x_val))
+        self.toxic = dict(alpha=al, beta=be, gamma=ga, delta=de, x=x)
+        zx = (pow(x, m, R) - 1) % R
+        if zx == 0 or de == 0:
+            raise ValueError("ScaleCRS: x must lie outside the evaluation domain and delta must be non-zero")
+        self.Zx = zx
+        dinv = pow(de, -1, R)
         lib = _lib.load()
-        S = _lib.ints_to_limbs(powers)
-        g1 = g1_to_limbs([G1])
-        g2 = g2_to_limbs([G2])
-        # sigma1_2 = [x^j]_1, sigma2_2 = [x^j]_2  (setup.py:18-23, 65-69)
-        s12 = np.zeros((m, 8), dtype=np.uint64)
-        _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(S), m, _lib.ptr(s12)))
-        s22 = np.zeros((m, 16), dtype=np.uint64)
-        _lib.check(lib.zk_fixed_base_g2(_lib.ptr(g2), _lib.ptr(S), m, _lib.ptr(s22)))
-        # sigma1_4: L query for private wires; placeholders (zeros) at the public indices (setup.py:42-54)
-        lq = [0 if i in circuit.pub else (beta * Ax[i] + alpha * Bx[i] + Cx[i]) % R * dinv % R for i in range(W)]
-        self.l_scalars = lq
-        s14 = np.zeros((W, 8), dtype=np.uint64)
-        _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(lq)), W, _lib.ptr(s14)))
-        for i in circuit.pub:
-            s14[i] = 0
-        # sigma1_5 = [x^k Z(x) / delta]_1, k < m - 1  (setup.py:56-60)
-        hq = [powers[k] * zx % R * dinv % R for k in range(m - 1)]
-        s15 = np.zeros((m - 1, 8), dtype=np.uint64)
-        _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(hq)), m - 1, _lib.ptr(s15)))
+        st = torch.cuda.current_stream().cuda_stream
+        fv = FrVec()
+        new = lambda rows: torch.empty((rows, 4), dtype=torch.int64, device="cuda")
+        one_row = _dev(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+        ones = one_row.repeat(m, 1)
+        omega = pow(5, (R - 1) // m, R)
+        roots = ones.clone()
+        fv.scale_powers(roots.data_ptr(), m, omega, st)                                   # w^k
+        # 1 / (x - w^k) for all k: pre[k] = prod_{j<k} d_j, suf[k] = prod_{j>=k} d_j, inverse = pre[k] * suf[k+1] / total
+        pre, suf = new(m + 1), new(m + 1)
+        pre[0] = one_row
+        suf[m] = one_row
+        FrVec.lincomb(pre[1:].data_ptr(), [roots.data_ptr()], [R - 1], m, constant=x, stream=st)      # d_k = x - w^k
+        suf[:m].copy_(pre[1:])
+        fv.scan(pre[1:].data_ptr(), m, product=True, reverse=False, stream=st)
+        fv.scan(suf.data_ptr(), m, product=True, reverse=True, stream=st)
+        total = _lib.limbs_to_ints(pre[m:m + 1].cpu().numpy().view(np.uint64))[0]
+        lag = new(m)
+        FrVec.mul(lag.data_ptr(), pre.data_ptr(), suf[1:].data_ptr(), m, st)
+        FrVec.mul(lag.data_ptr(), lag.data_ptr(), roots.data_ptr(), m, st)
+        FrVec.lincomb(lag.data_ptr(), [lag.data_ptr()], [zx * pow(m, -1, R) % R * pow(total, -1, R) % R], m, stream=st)   # L_k(x)
+        # per-wire QAP values: M_i(x) = sum_k M[k][i] L_k(x)
+        self.d_qap = {}
+        for name, csr in circuit.r1cs_csr().items():
+            self.d_qap[name] = _transposed_times(csr, W, lag, st)
+        # exponents of the L query (private wires; zero, i.e. the placeholder / infinity, at the public ones: setup.py:42-54)
+        lq = new(W)
+        FrVec.lincomb(lq.data_ptr(), [self.d_qap[k].data_ptr() for k in "ABC"], [be * dinv % R, al * dinv % R, dinv], W, stream=st)
+        lq[torch.from_numpy(np.array(circuit.pub, dtype=np.int64)).cuda()] = 0
+        self.d_l_scalars = lq
+        powers = ones                                                                     # x^j  (setup.py:18-23, 65-69)
+        fv.scale_powers(powers.data_ptr(), m, x, st)
+        hq = new(m - 1) if m > 1 else None                                                # x^k Z(x) / delta, k < m - 1  (setup.py:56-60)
+        if m > 1:
+            FrVec.lincomb(hq.data_ptr(), [powers.data_ptr()], [zx * dinv % R], m - 1, stream=st)
+        # sigma1_1 / sigma2_1 (setup.py:15-16, 62-63)
+        self.sigma1_1 = fixed_base_mul(G1, [al, be, de])
+        self.sigma2_1 = fixed_base_mul(G2, [be, ga, de])
+        g1, g2 = g1_to_limbs([G1]), g2_to_limbs([G2])
         # query arrays with the constant terms appended, so that a proof element is ONE device MSM:
         #   G1: sigma1_2 | alpha*G1 | delta*G1 | beta*G1        G2: sigma2_2 | beta*G2 | delta*G2
-        s12x = np.concatenate([s12, g1_to_limbs([self.sigma1_1[0], self.sigma1_1[2], self.sigma1_1[1]])])
-        s22x = np.concatenate([s22, g2_to_limbs([self.sigma2_1[0], self.sigma2_1[2]])])
-        self.d_s12, self.d_s22, self.d_s14, self.d_s15 = _dev(s12x), _dev(s22x), _dev(s14), _dev(s15)
+        self.d_s12 = torch.empty((m + 3, 8), dtype=torch.int64, device="cuda")
+        self.d_s22 = torch.empty((m + 2, 16), dtype=torch.int64, device="cuda")
+        self.d_s14 = torch.empty((W, 8), dtype=torch.int64, device="cuda")
+        self.d_s15 = torch.empty((max(m - 1, 0), 8), dtype=torch.int64, device="cuda")
+        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), powers.data_ptr(), m, self.d_s12.data_ptr(), st))
+        _lib.check(lib.zk_fixed_base_g2_dev(_lib.ptr(g2), powers.data_ptr(), m, self.d_s22.data_ptr(), st))
+        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), lq.data_ptr(), W, self.d_s14.data_ptr(), st))   # exponent 0 -> infinity (zeros)
+        if m > 1:
+            _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), hq.data_ptr(), m - 1, self.d_s15.data_ptr(), st))
+        self.d_s12[m:] = _dev(g1_to_limbs([self.sigma1_1[0], self.sigma1_1[2], self.sigma1_1[1]]))
+        self.d_s22[m:] = _dev(g2_to_limbs([self.sigma2_1[0], self.sigma2_1[2]]))
+        torch.cuda.synchronize()
+        fv.close()
 
 
 class ScaleProver:
@@ -193,6 +194,16 @@ class ScaleProver:
         self.h_consts = torch.empty((8, 4), dtype=torch.int64).pin_memory()
         self.d_consts = new(8)
         self.zinv = pow((pow(COSET_SHIFT, self.m, R) - 1) % R, -1, R)  # 1 / Z_H on the coset k*H
+        self.profile = None     # set_profiling(True): a dict the next proof fills with the GPU time of its parts (HIP events)
+
+    def set_profiling(self, enable):
+        """With profiling on, a proof (bound CRS) records where its GPU time goes: the span of the transform / quotient section on the
+        caller's stream (torch events) and, per MSM, the plan's stage spans {prepare, sort, accumulate, reduce}
+        (zk_msm_plan_stage_ms) with the MSMs run one at a time, so that a span holds that MSM's kernels only.  The sum is the
+        proof's kernel time; the pipelined wall clock of an unprofiled proof is measured separately."""
+        self.g1.set_profiling(enable)
+        self.g2.set_profiling(enable)
+        self.profile = {} if enable else None
 
     def prove(self, d_a, d_b, d_c, d_w, r, s, stream=None):
         """d_a, d_b, d_c: device (m, 4) evaluations sum_i w_i A[k][i] etc. (d_c is overwritten with the
@@ -221,6 +232,9 @@ class ScaleProver:
             self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
         # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.): 3 inverse NTTs, written where the MSMs read them (the
         # transforms run from one buffer to another: zk_ntt_dev_padded -- no copies)
+        if self.profile is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
         for src, dst in ((d_a, ua), (d_b, ub), (d_c, d_c)):
             self.ntt.run_padded(src.data_ptr(), dst.data_ptr(), m, True, None, st)
         self.ext_b2[:m].copy_(ub)
@@ -243,6 +257,17 @@ class ScaleProver:
             sc[self.off14:self.off15].copy_(d_w)                                         # placeholders at public wires are infinity
         # The MSMs, each in its own workspace and stream (the G1 plan keeps three in flight).  The G2 one leads: its long,
         # latency-bound bucket reduction then runs beside the G1 accumulate kernels instead of alone.
+        if self.profile is not None:
+            ev[1].record()
+        if self.profile is not None and self.bound:
+            # profiling: the three MSMs ONE AT A TIME (submit, collect, next), so that every stage span is the time of that MSM's own
+            # kernels and the sum is the proof's kernel time; the proof is the same, its wall clock is not the pipelined one
+            proof_b = self._pt(self.g2, self._collect(self.g2, self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st), "msm_B_g2"))
+            proof_a = self._pt(self.g1, self._collect(self.g1, self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st), "msm_A_g1"))
+            proof_c = self._pt(self.g1, self._collect(self.g1, self.g1.submit_bound(self.sc_c.data_ptr(), 0, self.n_c, st), "msm_C_g1_merged"))
+            torch.cuda.synchronize()
+            self.profile["transforms_and_quotient_ms"] = round(ev[0].elapsed_time(ev[1]), 4)
+            return proof_a, proof_b, proof_c, h
         t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
         t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
         if self.bound:
@@ -263,6 +288,12 @@ class ScaleProver:
         proof_c = msm_g1([s, r, 1, 1], [proof_a, msm_b1, msm_l, msm_h])
         return proof_a, proof_b, proof_c, h
 
+    def _collect(self, plan, ticket, name):
+        res = plan.collect_limbs(ticket)
+        if self.profile is not None:
+            self.profile[name] = dict(zip(("prepare", "sort", "accumulate", "reduce"), (round(v, 4) for v in plan.stage_ms())))
+        return res
+
     def _msm(self, plan, scalars, points, first, count, st):
         """Submit one query MSM: over the bound table when the CRS is bound (first = offset of the query in it)."""
         if self.bound:
@@ -282,10 +313,19 @@ class ScaleProver:
         import torch
         from ..device import fr_spmv
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        timed = self.profile is not None and stream is None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for name, out in zip("ABC", self.abc):
             rp, col, vals = self.r1cs[name]
             fr_spmv(rp.data_ptr(), col.data_ptr(), vals.data_ptr(), d_w.data_ptr(), out.data_ptr(), self.m, st)
-        return self.prove(self.abc[0], self.abc[1], self.abc[2], d_w, r, s, stream)
+        if timed:
+            e1.record()
+        res = self.prove(self.abc[0], self.abc[1], self.abc[2], d_w, r, s, stream)
+        if timed:
+            self.profile["sparse_matvecs_ms"] = round(e0.elapsed_time(e1), 4)
+        return res
 
     @staticmethod
     def _pt(plan, res):
@@ -358,18 +398,3 @@ class ShardedScaleProver(ScaleProver):
         proof_b = fold_partials(_lib.GROUP_G2, np.ascontiguousarray(everyone[:, 64:96]))
         proof_c = msm_g1([s, r, 1, 1], [proof_a, msm_b1, msm_l, msm_h])
         return proof_a, proof_b, proof_c, h
-
-
-def closed_form_scalars(crs, witness, r, s):
-    """(A, B, C) in F_r with proof_A = A*G1, proof_B = B*G2, proof_C = C*G1  (zkp/groth16/test.py:303-325)."""
-    t = crs.toxic
-    W = crs.circuit.num_wires
-    a_x = sum(witness[i] * crs.Ax[i] for i in range(W)) % R
-    b_x = sum(witness[i] * crs.Bx[i] for i in range(W)) % R
-    c_x = sum(witness[i] * crs.Cx[i] for i in range(W)) % R
-    A = (t["alpha"] + a_x + r * t["delta"]) % R
-    B = (t["beta"] + b_x + s * t["delta"]) % R
-    h_x = (a_x * b_x - c_x) % R * pow(crs.Zx, -1, R) % R
-    priv = sum(witness[i] * crs.l_scalars[i] for i in range(W)) % R   # already divided by delta, public entries are 0
-    C = (priv + h_x * crs.Zx % R * pow(t["delta"], -1, R) + A * s + B * r - r * s * t["delta"]) % R
-    return A, B, C

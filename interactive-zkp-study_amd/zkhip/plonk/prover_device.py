@@ -45,7 +45,8 @@ def _limbs(ints):
 
 class DevicePlonk:
     """Circuit of n = 2^k gates given by its selector and permutation EVALUATIONS on the domain (limb arrays
-    (n, 4) uint64: q_l, q_r, q_o, q_m, q_c, s_sigma1..3) and an SRS as a limb array of G1 points (>= n + 6 rows)."""
+    (n, 4) uint64, or device tensors (n, 4) int64: q_l, q_r, q_o, q_m, q_c, s_sigma1..3) and an SRS as a limb array / device
+    tensor of G1 points (>= n + 6 rows)."""
 
     def __init__(self, selectors, sigmas, srs_g1_limbs):
         torch = _torch()
@@ -65,14 +66,19 @@ class DevicePlonk:
         self.ntt_n = NttPlan(self.log_n)
         self.ntt_big = NttPlan(self.size.bit_length() - 1)
         self.msm = MsmPlan(_lib.GROUP_G1, n + PAD)
-        self.srs = _dev(srs_g1_limbs[:n + PAD] if srs_g1_limbs.shape[0] >= n + PAD else np.concatenate(
-            [srs_g1_limbs, np.zeros((n + PAD - srs_g1_limbs.shape[0], 8), dtype=np.uint64)]))
+        if torch.is_tensor(srs_g1_limbs):
+            self.srs = torch.zeros((n + PAD, 8), dtype=torch.int64, device="cuda")
+            rows = min(n + PAD, srs_g1_limbs.shape[0])
+            self.srs[:rows] = srs_g1_limbs[:rows]
+        else:
+            self.srs = _dev(srs_g1_limbs[:n + PAD] if srs_g1_limbs.shape[0] >= n + PAD else np.concatenate(
+                [srs_g1_limbs, np.zeros((n + PAD - srs_g1_limbs.shape[0], 8), dtype=np.uint64)]))
         # the SRS never changes: bind it (table of 2^(20 w) * [tau^i], 13 n bucket additions per commitment instead of 16 n)
         self.bound = n + PAD > (1 << 17)
         if self.bound:
             self.msm.bind(self.srs.data_ptr(), n + PAD, self.st)
         names = ("q_l", "q_r", "q_o", "q_m", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")
-        self.evals = {k: _dev(v) for k, v in zip(names, list(selectors) + list(sigmas))}
+        self.evals = {k: (v if torch.is_tensor(v) else _dev(v)) for k, v in zip(names, list(selectors) + list(sigmas))}
         # coefficient forms (8 inverse NTTs) and commitments (8 MSMs)
         self.coef, self.comm = {}, {}
         for k in names:
@@ -91,7 +97,7 @@ class DevicePlonk:
         x_coef[1:2] = _dev(_limbs([1]))
         self.coset["x"] = self._coset(x_coef)
         l1_coef = self._zeros(n + PAD)
-        l1_coef[:n] = _dev(_limbs([pow(n, -1, R)] * n))          # L_1(x) = (x^n - 1) / (n (x - 1)) = (1/n) sum_j x^j
+        l1_coef[:n] = _dev(_limbs([pow(n, -1, R)]))              # L_1(x) = (x^n - 1) / (n (x - 1)) = (1/n) sum_j x^j  (one row, broadcast)
         self.coset["l1"] = self._coset(l1_coef)
         w_big = int(get_root_of_unity(self.size))
         zh_inv = [pow((pow(COSET_K * pow(w_big, i, R) % R, n, R) - 1) % R, -1, R) for i in range(self.step)]

@@ -573,3 +573,21 @@ void orc_fr_dot(const uint64_t *a, const uint64_t *b, size_t n, uint64_t out[4])
     }
     memcpy(out, &acc, 32);
 }
+
+/* y = M x over F_r for a CSR matrix (row_ptr u32[rows+1], col u32[nnz], vals nnz x 4 limbs canonical): the per-constraint dot
+ * products A.w, B.w, C.w of an R1CS -- what the reference's `_multiply_vec_matrix` (zkp/groth16/poly_utils.py:52-59) computes
+ * from its dense matrices.  Canonical in and out. */
+void orc_fr_spmv(const uint32_t *row_ptr, const uint32_t *col, const uint64_t *vals, const uint64_t *x, size_t rows, uint64_t *y) {
+    ensure_init();
+    for (size_t k = 0; k < rows; k++) {
+        fe acc = {{0, 0, 0, 0}}, a, b, t;
+        for (uint32_t e = row_ptr[k]; e < row_ptr[k + 1]; e++) {
+            memcpy(&a, vals + 4 * (size_t)e, 32); memcpy(&b, x + 4 * (size_t)col[e], 32);
+            f_to_mont(&FR, &a, &a);
+            f_mul(&FR, &t, &a, &b); /* (aR) * b / R = a * b canonical */
+            f_add(&FR, &acc, &acc, &t);
+        }
+        memcpy(y + 4 * k, &acc, 32);
+    }
+}
+

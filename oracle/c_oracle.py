@@ -199,3 +199,16 @@ def fr_dot_arr(a, b):
     O = np.zeros(4, dtype=np.uint64)
     lib().orc_fr_dot(_p(a), _p(b), ctypes.c_size_t(a.shape[0]), _p(O))
     return from_limbs(O)[0]
+
+
+def fr_spmv_arr(row_ptr, col, vals, x):
+    """y = M x over F_r, M in CSR form (row_ptr uint32[rows+1], col uint32[nnz], vals (nnz,4) uint64), x (n,4) uint64 -> (rows,4)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    vals = np.ascontiguousarray(vals, dtype=np.uint64)
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    rows = row_ptr.shape[0] - 1
+    y = np.zeros((rows, 4), dtype=np.uint64)
+    lib().orc_fr_spmv(_p(row_ptr), _p(col), _p(vals), _p(x), ctypes.c_size_t(rows), _p(y))
+    return y
+

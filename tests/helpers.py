@@ -50,4 +50,4 @@ from zkhip.synthetic import arithmetic_dot, arithmetic_points as arithmetic_g1_p
 
 
 # Oracle-side expectations for the at-scale Groth16 prover (BASELINE.json configs[3]): oracle/scale_ref.py
-from scale_ref import chain_closed_form_oracle, chain_crs_scalars, chain_witness, lagrange_at  # noqa: E402,F401
+from scale_ref import lagrange_at, r1cs_closed_form, r1cs_crs_scalars  # noqa: E402,F401

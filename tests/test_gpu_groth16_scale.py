@@ -7,9 +7,9 @@ import pytest
 
 import c_oracle as co
 import py_ref as o
-from helpers import chain_closed_form_oracle, chain_crs_scalars, chain_witness
+from helpers import r1cs_closed_form, r1cs_crs_scalars
 from zkhip import _lib
-from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver, closed_form_scalars
+from zkhip.groth16.prover_ntt import BoolChainCircuit, ChainCircuit, ScaleCRS, ScaleProver
 
 pytestmark = pytest.mark.gpu
 
@@ -34,8 +34,7 @@ def _ints(pt):
 def _oracle_proof(circ, x_val, w, r, s):
     """(A*G1, B*G2, C*G1) with the scalars AND the points from the oracle (zkp/groth16/test.py:303-325); nothing of the
     library's CRS, field layer or group kernels is involved in the expectation."""
-    assert w == chain_witness(circ.consts, circ.t0)
-    A, B, C = chain_closed_form_oracle(circ.consts, w, dict(TOXIC, x=x_val), r, s)
+    A, B, C = r1cs_closed_form(circ.r1cs_csr(), w, circ.pub, dict(TOXIC, x=x_val), r, s)
     return co.g1_mul(o.G1, A), co.g2_mul(o.G2, B), co.g1_mul(o.G1, C)
 
 
@@ -43,8 +42,11 @@ def _check_crs_against_oracle(crs, x_val):
     """A few elements of every device-built query (zkp/groth16/setup.py:18-69) against the oracle's k*G."""
     circ = crs.circuit
     m, W = circ.m, circ.num_wires
-    i12, i14, i15 = [0, 1, m // 3, m - 1], [2, 3, W // 2, W - 2, W - 1], [0, 1, m // 2, m - 2]
-    k12, k14, k15 = chain_crs_scalars(circ.consts, dict(TOXIC, x=x_val), i12, i14, i15)
+    if m <= 1024:                                                        # every element of every query
+        i12, i14, i15 = list(range(m)), [i for i in range(W) if i not in circ.pub], list(range(m - 1))
+    else:
+        i12, i14, i15 = [0, 1, m // 3, m - 1], [2, 3, W // 2, W // 2 + 1, W - 2, W - 1], [0, 1, m // 2, m - 2]
+    k12, k14, k15 = r1cs_crs_scalars(circ.r1cs_csr(), dict(TOXIC, x=x_val), i12, i14, i15)
     rows = lambda t, idx: t[idx].cpu().numpy().view(np.uint64)
     assert np.array_equal(rows(crs.d_s12, i12), co.g1_fixed_base_arr(o.G1, co.to_limbs(k12)))
     assert np.array_equal(rows(crs.d_s22, i12), co.g2_fixed_base_arr(o.G2, co.to_limbs(k12)))
@@ -57,10 +59,10 @@ def _check_crs_against_oracle(crs, x_val):
     assert np.array_equal(rows(crs.d_s22, [m, m + 1]), co.g2_fixed_base_arr(o.G2, co.to_limbs([t["beta"], t["delta"]])))
 
 
-@pytest.mark.parametrize("log_m", [4, 10, 13])
-def test_scale_prover_closed_form(log_m):
+@pytest.mark.parametrize("kind,log_m", [("chain", 4), ("chain", 10), ("chain", 13), ("bool", 1), ("bool", 5), ("bool", 10), ("bool", 13)])
+def test_scale_prover_closed_form(kind, log_m):
     import torch
-    circ = ChainCircuit(log_m, seed=3)
+    circ = (ChainCircuit if kind == "chain" else BoolChainCircuit)(log_m, seed=3)
     x_val = 3721 + (1 << 200)
     crs = ScaleCRS(circ, x_val=x_val, **TOXIC)
     _check_crs_against_oracle(crs, x_val)
@@ -71,7 +73,6 @@ def test_scale_prover_closed_form(log_m):
     d_a, d_b, d_c, d_w = _dev(a), _dev(b), _dev(c), _dev(w)
     pa, pb, pc, h = prover.prove(d_a, d_b, d_c, d_w, r, s)
     assert (_ints(pa), _ints(pb), _ints(pc)) == _oracle_proof(circ, x_val, w, r, s)
-    assert closed_form_scalars(crs, w, r, s) == chain_closed_form_oracle(circ.consts, w, dict(TOXIC, x=x_val), r, s)
     # the same proof from the witness alone: A.w, B.w, C.w by the device mat-vec (prove() consumed d_a..d_c in place)
     prover.load_r1cs(circ.r1cs_csr())
     qa, qb, qc, _ = prover.prove_from_witness(d_w, r, s)
@@ -79,7 +80,7 @@ def test_scale_prover_closed_form(log_m):
     torch.cuda.synchronize()
     hc = _lib.limbs_to_ints(h.cpu().numpy().view(np.uint64))
     assert hc[circ.m - 1] == 0                                   # deg H <= m - 2
-    if log_m <= 4:
+    if log_m <= 5:
         # H against the reference's algorithm: (u_A * u_B - u_C) div (x^m - 1), remainder 0
         m = circ.m
         w_m = o.get_root_of_unity(m)

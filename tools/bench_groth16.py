@@ -18,26 +18,33 @@ def proof_equals_oracle(circ, toxic, w, r, s, proof):
     import c_oracle as co
     import py_ref
     import scale_ref
-    A, B, C = scale_ref.chain_closed_form_oracle(circ.consts, w, toxic, r, s)
+    A, B, C = scale_ref.r1cs_closed_form(circ.r1cs_csr(), w, circ.pub, toxic, r, s)
     pa, pb, pc = proof
     g1 = lambda p: None if p is None else (int(p[0]), int(p[1]))
     g2 = lambda p: None if p is None else tuple(tuple(int(c) for c in v.coeffs) for v in p)
     return g1(pa) == co.g1_mul(py_ref.G1, A) and g2(pb) == co.g2_mul(py_ref.G2, B) and g1(pc) == co.g1_mul(py_ref.G1, C)
 
 
-def run(log_m, reps, lib_path=""):
+def run(log_m, reps, lib_path="", circuit="chain"):
+    """circuit: "chain" (uniform witness) or "bool" (half of the wires are bits: zkhip.groth16.circuits.BoolChainCircuit)."""
     import torch
     from zkhip import _lib
     if lib_path:
         _lib.LIB_PATH = lib_path   # another build of libzkhip.so, for same-session A/B runs
-    from zkhip.groth16.prover_ntt import ChainCircuit, ScaleCRS, ScaleProver
+    from zkhip.groth16.prover_ntt import BoolChainCircuit, ChainCircuit, ScaleCRS, ScaleProver
     t0 = time.perf_counter()
-    circ = ChainCircuit(log_m, seed=7)
+    circ = (BoolChainCircuit if circuit == "bool" else ChainCircuit)(log_m, seed=7)
     w, a, b, c = circ.witness()
     t_wit = time.perf_counter() - t0
     t0 = time.perf_counter()
     toxic = dict(alpha=3926, beta=3604, gamma=2971, delta=1357, x=3721 + (1 << 201))
     crs = ScaleCRS(circ, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["x"])
+    torch.cuda.synchronize()
+    t_setup_first = time.perf_counter() - t0            # includes what a process pays once: code objects, first launches, torch's index kernels
+    del crs
+    t0 = time.perf_counter()
+    crs = ScaleCRS(circ, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["x"])
+    torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
     prover = ScaleProver(crs)
     dev = lambda v: torch.from_numpy(_lib.ints_to_limbs(v).view(np.int64)).cuda()
@@ -54,9 +61,24 @@ def run(log_m, reps, lib_path=""):
     # the per-constraint values the device mat-vec produced, against the host's
     same_abc = all(torch.equal(x, y) for x, y in ((prover.abc[0], A0), (prover.abc[1], B0)))
     ok = same_abc and proof_equals_oracle(circ, toxic, w, r, s, (pa, pb, pc))
-    return {"log_m": log_m, "constraints": circ.m, "wires": circ.num_wires, "prove_ms": round(min(times[1:]) * 1e3, 3),
+    # two more proofs with HIP events around their parts and the MSMs one at a time: the proof's kernel time by parts (the second
+    # one counts: the first creates the events), next to the pipelined wall clock above
+    prover.set_profiling(True)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        again = prover.prove_from_witness(W0, r, s)[:3]
+        torch.cuda.synchronize()
+        wall_prof = (time.perf_counter() - t0) * 1e3
+    parts = dict(prover.profile)
+    kernel_sum = sum(v if not isinstance(v, dict) else sum(v.values()) for v in parts.values())
+    prover.set_profiling(False)
+    bits = sum(1 for v in w if v in (0, 1))
+    return {"circuit": circuit, "witness_wires_in_0_1": bits, "same_proof_with_profiling": bool(again == (pa, pb, pc)),
+            "kernel_ms_by_parts_serialized": parts, "kernel_ms_sum": round(kernel_sum, 3), "wall_ms_serialized_profiled": round(wall_prof, 3),
+            "log_m": log_m, "constraints": circ.m, "wires": circ.num_wires, "prove_ms": round(min(times[1:]) * 1e3, 3),
             "prove_ms_all": [round(t * 1e3, 3) for t in times[1:]], "first_call_ms": round(times[0] * 1e3, 3),
-            "witness_gen_s_python": round(t_wit, 2), "setup_s": round(t_setup, 2), "verified_closed_form": bool(ok)}
+            "witness_gen_s_python": round(t_wit, 2), "setup_s": round(t_setup, 3), "setup_s_first_call_in_process": round(t_setup_first, 3), "verified_closed_form": bool(ok)}
 
 
 if __name__ == "__main__":
@@ -64,5 +86,6 @@ if __name__ == "__main__":
     ap.add_argument("--log-m", type=int, default=20)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--lib", default="")
+    ap.add_argument("--circuit", default="chain", choices=["chain", "bool"])
     args = ap.parse_args()
-    print(json.dumps(run(args.log_m, args.reps, args.lib)), flush=True)
+    print(json.dumps(run(args.log_m, args.reps, args.lib, args.circuit)), flush=True)

@@ -31,30 +31,47 @@ def run(log_n, reps, profile=False):
         cur = cur * ys[i] % R if i % 2 == 0 else (cur + ys[i]) % R
         c[i] = cur
     t_wit = time.perf_counter() - t0
+    def preprocess():
+        lib = _lib.load()
+        from zkhip.device import FrVec
+        st = torch.cuda.current_stream().cuda_stream
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+        two = _lib.ints_to_limbs([0, 1, R - 1])                                             # the values the selector columns take
+        col = lambda even_val, odd_val: up(np.tile(np.stack([two[even_val], two[odd_val]]), (n // 2, 1)))
+        sel = [col(0, 1), col(0, 1), col(2, 2), col(1, 0), col(0, 0)]                        # q_l, q_r, q_o, q_m, q_c
+        # labels omega^i on the device (zk_fr_scale_powers_dev), the permutation columns as shifted multiples of them:
+        # sigma: c_{i-1} <-> a_i swapped, everything else fixed
+        fv = FrVec()
+        ones = up(np.tile(two[1], (n + 8, 1)))
+        dom = ones[:n].clone()
+        fv.scale_powers(dom.data_ptr(), n, int(get_root_of_unity(n)), st)
+        s1, s2, s3 = (torch.empty_like(dom) for _ in range(3))
+        FrVec.lincomb(s1[1:].data_ptr(), [dom.data_ptr()], [3], n - 1, stream=st)           # a_i  -> position of c_{i-1}: 3 * omega^(i-1)
+        s1[:1] = dom[:1]                                                                      # a_0  -> itself
+        FrVec.lincomb(s2.data_ptr(), [dom.data_ptr()], [2], n, stream=st)                    # b_i  -> itself: 2 * omega^i
+        s3[:n - 1] = dom[1:]                                                                  # c_i  -> position of a_{i+1}: omega^(i+1)
+        FrVec.lincomb(s3[n - 1:].data_ptr(), [dom[n - 1:].data_ptr()], [3], 1, stream=st)    # c_{n-1} -> itself
+        sig = [s1, s2, s3]
+        # SRS: [tau^i]_1, the exponents by zk_fr_scale_powers_dev, the points by the fixed-base batch on device buffers (srs.py:77-85)
+        tau = 0xC0FFEE1234567
+        powers = ones
+        fv.scale_powers(powers.data_ptr(), n + 8, tau, st)
+        P = torch.empty((n + 8, 8), dtype=torch.int64, device="cuda")
+        g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
+        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), powers.data_ptr(), n + 8, P.data_ptr(), st))
+        fv.close()
+        dev = DevicePlonk(sel, sig, P)
+        return dev, tau
+
     t0 = time.perf_counter()
-    lib = _lib.load()
-    col = lambda even_val, odd_val: _lib.ints_to_limbs([even_val, odd_val] * (n // 2))
-    sel = [col(0, 1), col(0, 1), col(R - 1, R - 1), col(1, 0), col(0, 0)]                # q_l, q_r, q_o, q_m, q_c
-    # labels: omega^i via one device batch k_i * 1 is overkill -- powers in Python are the setup cost here
-    w = int(get_root_of_unity(n))
-    dom, curw = [0] * n, 1
-    for i in range(n):
-        dom[i] = curw
-        curw = curw * w % R
-    # sigma: c_{i-1} <-> a_i swapped, everything else fixed
-    s1 = [dom[0]] + [3 * dom[i - 1] % R for i in range(1, n)]          # a_i  -> position of c_{i-1}
-    s2 = [2 * d % R for d in dom]                                        # b_i  -> itself
-    s3 = [dom[i + 1] for i in range(n - 1)] + [3 * dom[n - 1] % R]      # c_i  -> position of a_{i+1}
-    sig = [_lib.ints_to_limbs(s) for s in (s1, s2, s3)]
-    tau = 0xC0FFEE1234567
-    powers, t = [0] * (n + 8), 1
-    for i in range(n + 8):
-        powers[i] = t
-        t = t * tau % R
-    P = np.zeros((n + 8, 8), dtype=np.uint64)
-    g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
-    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(g1), _lib.ptr(_lib.ints_to_limbs(powers)), n + 8, _lib.ptr(P)))
-    dev = DevicePlonk(sel, sig, P)
+    dev, tau = preprocess()
+    torch.cuda.synchronize()
+    t_pre_first = time.perf_counter() - t0              # includes what a process pays once (code objects, first launches)
+    del dev
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    dev, tau = preprocess()
+    torch.cuda.synchronize()
     t_pre = time.perf_counter() - t0
     cols = [torch.from_numpy(_lib.ints_to_limbs(v).view(np.int64)).cuda() for v in (a, ys, c)]
     # the witness above lives in Python lists of 2^20 ints: park those objects outside the collector, or a generation-2 sweep
@@ -88,7 +105,7 @@ def run(log_n, reps, profile=False):
     mismatches = dev.closed_form_mismatches(proof, tau)
     return {"commitments_equal_p_of_tau_times_G1": not mismatches, "commitment_mismatches": mismatches,
             "log_n": log_n, "gates": n, "prove_ms": round(min(times[1:]) * 1e3, 3), "prove_ms_all": [round(t * 1e3, 3) for t in times[1:]],
-            "first_call_ms": round(times[0] * 1e3, 3), "witness_gen_s_python": round(t_wit, 2), "preprocess_s": round(t_pre, 2), "verified": bool(ok)}
+            "first_call_ms": round(times[0] * 1e3, 3), "witness_gen_s_python": round(t_wit, 2), "preprocess_s": round(t_pre, 3), "preprocess_s_first_call_in_process": round(t_pre_first, 3), "verified": bool(ok)}
 
 
 if __name__ == "__main__":
