@@ -144,8 +144,10 @@ int zk_ntt_fr(uint64_t *data /* n*4, in place, HOST */, unsigned log_n, int inve
 /* The host-buffer entry points (zk_msm_g1 / zk_msm_g2 / zk_ntt_fr: what the reference-signature facade calls once per commit /
  * proof element / fft) keep their plans -- NTT tables per log_n, MSM workspaces per group and power-of-two size class, plus the
  * staging buffers -- per calling thread and device, a handful of each (least recently used first out), so that only the first
- * call of a size pays for table building and allocation (MSMs of more than 2^24 points and transforms of more than 2^24
- * elements are not kept: their plan lives for the call).  zk_cache_clear drops the calling thread's cache (device memory is
+ * call of a size pays for table building and allocation (MSMs of more than 2^20 points and transforms of more than 2^22
+ * elements are not kept: their plan lives for the call; what a thread retains is bounded by three MSM size classes per group of at
+ * most 2^20 points and six NTT plans of at most 2^22 elements -- a few GB of HBM in the worst case, returned by zk_cache_clear or at
+ * thread exit).  zk_cache_clear drops the calling thread's cache (device memory is
  * returned); zk_cache_stats reports {NTT plans built, NTT cache hits, MSM plans built, MSM cache hits} of the calling thread. */
 int zk_cache_clear(void);
 int zk_cache_stats(uint64_t out[4]);

@@ -317,10 +317,13 @@ static thread_local std::map<std::pair<int, int>, std::vector<std::unique_ptr<Ho
 static thread_local std::map<std::pair<int, unsigned>, std::unique_ptr<HostNttCtx>> g_ntt_cache;            // (device, log_n)
 static thread_local uint64_t g_cache_clock = 0;
 constexpr size_t MSM_CACHE_PER_GROUP = 3, NTT_CACHE_PLANS = 6;
-// Calls beyond these sizes build their plan for the call and release it afterwards: a one-off 2^26-point host-buffer MSM must not
-// leave 10 GB of staging buffer and workspace behind in the calling thread.
-constexpr size_t MSM_CACHE_MAX_POINTS = (size_t)1 << 24;
-constexpr unsigned NTT_CACHE_MAX_LOG = 24;
+// Calls beyond these sizes build their plan for the call and release it afterwards, so that what a thread can leave pinned in HBM
+// stays modest: per group at most three size classes of at most 2^20 points (staging 96 / 160 B per point plus one lane's workspace,
+// about 0.5 GB for G1 and 1.2 GB for G2 at the largest class) and six NTT plans of at most 2^22 elements (128 MB of staging plus
+// as much scratch each) -- a few GB in the worst case, against several GB PER CALL SIZE before round 4.  The facade works at the
+// reference's toy sizes; provers at scale hold their own plans (zk_msm_plan_create / zk_ntt_plan_create).
+constexpr size_t MSM_CACHE_MAX_POINTS = (size_t)1 << 20;
+constexpr unsigned NTT_CACHE_MAX_LOG = 22;
 
 static HostMsmCtx &host_msm_ctx(int group, size_t n, size_t point_bytes) {
     int dev = 0;

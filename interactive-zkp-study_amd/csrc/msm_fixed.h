@@ -146,7 +146,7 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
     const uint32_t t = threadIdx.x;
     const uint32_t v0 = blockIdx.x * NE;
     // span starts of this thread's two cells: every workgroup scans the 2048 cell totals of the prepare kernel itself (no scan launch
-    // in between; workgroup 0 publishes them for the cell sort, msm_segcount_kernel zeroes the counters for the next run)
+    // in between; workgroup 0 publishes them for the cell sort, msm_cellsort_kernel zeroes the counters for the next run)
     uint32_t cb0, cb1;
     {
         const uint32_t c0 = B.cell_total[2 * t], c1 = B.cell_total[2 * t + 1];

@@ -127,10 +127,10 @@ constexpr uint32_t HEAVY_BLOCKS = 1024;     // workgroups at the head of the acc
 struct SortBufs {
     uint32_t *counts;       // [W*nb]   list length of every bucket
     uint32_t *bucket_off;   // [W*nb]   start of every bucket's list inside sorted[]
-    uint32_t *cell_total;   // [cells]  entries per cell; accumulated by prepare, zeroed by msm_segcount_kernel
+    uint32_t *cell_total;   // [cells]  entries per cell; accumulated by prepare, zeroed by msm_cellsort_kernel
     uint32_t *cell_base;    // [cells]  exclusive scan of the padded cell_total (published by partition workgroup 0)
     uint32_t *cell_cnt;     // [cells]  copy of cell_total for the later passes
-    uint32_t *cell_cursor;  // [cells]  partition write cursors (zeroed by msm_segcount_kernel)
+    uint32_t *cell_cursor;  // [cells]  partition write cursors (zeroed by msm_cellsort_kernel)
     uint32_t *e_idx;        // [W*n]    partitioned entries: point index | sign << 31
     uint8_t *e_loc;         // [W*n]    partitioned entries: bucket index inside the cell
     uint32_t *sorted;       // [W*n]    entries grouped by bucket
@@ -147,7 +147,7 @@ struct SortBufs {
     uint32_t *heavy_ctr;    // [2] number of heavy tasks, number of heavy buckets (zeroed by the scan kernel)
     uint32_t *big_ctr;      // [1] cells too large for msm_cellsort_kernel (zeroed by the scan kernel)
     uint32_t *big_cells;    // [cells] their ids: the work list of msm_segcount_kernel / msm_segscatter_kernel
-    uint2 *heavy_tasks;     // [heavy_cap] (bucket id, segment index)
+    uint2 *heavy_tasks;     // [heavy_cap] (heavy-bucket slot, 64-segment group of its list)
     uint4 *heavy_buckets;   // [heavy_cap] (bucket id, first task, segments, -)
     // Device-side error counter of the lane (never reset: the host compares it with the value it saw last).  Bumped when an
     // input breaks a precondition the host cannot check on device buffers (a scalar >= 2^255: the signed-digit carry leaves
@@ -877,15 +877,21 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
     // A launch that throws half-way through a submission must not leave the lane marked busy, and whatever the kernels that did
     // start added to the lane's device error counter must not be charged to the next (valid) submission: wait for the lane and
     // re-read the counter.
+    // The sort counters (cell totals / cursors, list-length histogram, heavy-task and big-cell counters) are zeroed by the kernels
+    // that consume them, i.e. only by a launch sequence that ran to its end: after a failure they are reset here, or the lane's
+    // next MSM would be partitioned from stale totals.
     struct LaneGuard {
         Lane *lane;
         ~LaneGuard() {
             if (!lane) return;
             lane->busy = false;
             uint32_t now = 0;
-            if (lane->stream && hipStreamSynchronize(lane->stream) == hipSuccess &&
-                hipMemcpy(&now, lane->out.p, sizeof(now), hipMemcpyDeviceToHost) == hipSuccess)
-                lane->err_seen = now;
+            if (lane->stream && hipStreamSynchronize(lane->stream) == hipSuccess) {
+                (void)hipMemset(lane->cells.p, 0, lane->cells.bytes);
+                (void)hipMemset(lane->size_bins.p, 0, lane->size_bins.bytes);
+                (void)hipDeviceSynchronize();
+                if (hipMemcpy(&now, lane->out.p, sizeof(now), hipMemcpyDeviceToHost) == hipSuccess) lane->err_seen = now;
+            }
         }
     };
     static constexpr int MAX_LANES = 3;
@@ -1094,10 +1100,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         fix_n = n;
         return ZK_OK;
     }
+    // The first free lane, scanning from next_lane (tickets are collected in any order, so the lane after the one used last may still
+    // be busy while others are free); throws only when every lane holds an uncollected submission.
+    int pick_lane() {
+        for (int k = 0; k < nlanes; k++)
+            if (!lanes[(next_lane + k) % nlanes].busy) return (next_lane + k) % nlanes;
+        throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect one first");
+    }
     int submit_lane_fixed(const void *d_scalars, size_t first, size_t n, hipStream_t st) {
-        const int ticket = next_lane;
+        const int ticket = pick_lane();
         Lane &L = lanes[ticket];
-        if (L.busy) throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect the oldest first");
         prepare_lane(L);
         const uint32_t n_pad = (uint32_t)pad_n(n);
         if (L.digits32.bytes < (size_t)FIX_W * pad_n(cap_n) * sizeof(int32_t)) L.digits32.alloc((size_t)FIX_W * pad_n(cap_n) * sizeof(int32_t));
@@ -1106,7 +1118,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         L.profiled = profile;
         L.single_window = true;
         L.c = FIX_C;
-        next_lane = (next_lane + 1) % nlanes;
+        next_lane = (ticket + 1) % nlanes;
         LaneGuard guard{&L};   // a launch that throws must not leave the lane marked busy
         hipStream_t ls = L.stream;
         ZK_HIP(hipEventRecord(L.ev_in, st));
@@ -1199,15 +1211,14 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         big.active = false;
     }
     int submit_lane(const void *d_scalars, const void *d_points, size_t n, hipStream_t st) {
-        const int ticket = next_lane;
+        const int ticket = pick_lane();
         Lane &L = lanes[ticket];
-        if (L.busy) throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect the oldest first");
         prepare_lane(L);
         L.busy = true;
         L.empty = (n == 0);
         L.profiled = profile;
         L.single_window = false;
-        next_lane = (next_lane + 1) % nlanes;
+        next_lane = (ticket + 1) % nlanes;
         if (n == 0) return ticket;
         LaneGuard guard{&L};
         const int c = pick_window_bits(n);

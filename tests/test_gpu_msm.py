@@ -433,6 +433,20 @@ def test_chunked_msm_small_chunks():
     assert np.array_equal(plan.collect_limbs(ta)[0], want_a)
     assert np.array_equal(plan.collect_limbs(tc)[0], want)
     assert np.array_equal(plan.collect_limbs(tb)[0], want_b)
+    # lanes are taken wherever one is free: A outstanding, a chunked MSM collected, and the next submission must not be refused
+    # because the rotation happens to point at A's lane (it was, with two lanes free, until round 4)
+    ta = plan.submit(dS.data_ptr(), dP.data_ptr(), 3000, st)
+    tc = plan.submit(dS.data_ptr(), dP.data_ptr(), n, st)
+    assert np.array_equal(plan.collect_limbs(tc)[0], want)
+    tb = plan.submit(dS.data_ptr() + 32 * 100, dP.data_ptr() + 64 * 100, 2000, st)
+    td = plan.submit(dS.data_ptr(), dP.data_ptr(), 3000, st)       # A, B and D outstanding: every lane taken
+    with pytest.raises(_lib.ZkhipError):
+        plan.submit(dS.data_ptr(), dP.data_ptr(), 100, st)
+    assert np.array_equal(plan.collect_limbs(tb)[0], want_b)
+    te = plan.submit(dS.data_ptr() + 32 * 100, dP.data_ptr() + 64 * 100, 2000, st)   # B's lane again, A and D still out
+    assert np.array_equal(plan.collect_limbs(ta)[0], want_a)
+    assert np.array_equal(plan.collect_limbs(te)[0], want_b)
+    assert np.array_equal(plan.collect_limbs(td)[0], want_a)
     t3 = [plan.submit(dS.data_ptr(), dP.data_ptr(), 3000, st) for _ in range(3)]
     with pytest.raises(_lib.ZkhipError):
         plan.submit(dS.data_ptr(), dP.data_ptr(), n, st)           # no lane free at all
