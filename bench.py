@@ -325,6 +325,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         world = dist.get_world_size()                                  # n_gpus of the line = what the process group reports
+        # which physical devices the ranks sit on: every rank contributes its device's UUID (PCI bus id where the runtime has none),
+        # so that a scaling line proves N distinct GPUs (or shows a rehearsal's shared one)
+        props = torch.cuda.get_device_properties(dev_index)
+        my_dev = str(getattr(props, "uuid", None) or "pci:%s:%s:%s" % (getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"),
+                                                                          getattr(props, "pci_device_id", "?")))
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "host": socket.gethostname(), "device": my_dev, "local_index": dev_index})
         host_group = dist.new_group(backend="gloo") if (args.exchange == "host" and not rehearsal) else None
 
     # ---- synthetic workload, generated once and left resident in HBM
@@ -846,6 +853,7 @@ def main():
             "extra": extra,
         }
         if dist_on:
+            line["config"]["ranks_seen"] = {"ranks": len(seen), "distinct_devices": len({(r["host"], r["device"]) for r in seen}), "by_rank": seen}
             line["config"]["collectives"] = ("gloo, ranks share %d device(s): REHEARSAL, not a scaling measurement" % visible if rehearsal else
                                              "RCCL (nccl backend)" + ("; MSM partials over a host-side gloo group (--exchange host)" if host_group is not None else ""))
         print(json.dumps(line), flush=True)

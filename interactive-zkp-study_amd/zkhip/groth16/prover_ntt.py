@@ -38,12 +38,27 @@ def _dev(arr):
 SPLIT = 1024   # longest run of entries one thread of the sparse mat-vec walks (see _transposed_times)
 
 
+def _run_pointers(lens):
+    """lens[i] consecutive entries belong to group i -> (ptr of the runs of at most SPLIT entries the groups are cut into, runs per group)."""
+    import torch
+    dev = lens.device
+    starts = torch.cumsum(lens, 0) - lens
+    runs = (lens + SPLIT - 1) // SPLIT
+    run_first = torch.cumsum(runs, 0) - runs
+    n_runs = int(runs.sum())
+    group_of_run = torch.repeat_interleave(torch.arange(lens.shape[0], device=dev), runs)
+    ptr = torch.empty(n_runs + 1, dtype=torch.int64, device=dev)
+    ptr[:n_runs] = starts[group_of_run] + SPLIT * (torch.arange(n_runs, device=dev) - run_first[group_of_run])
+    ptr[n_runs] = int(lens.sum())
+    return ptr, runs
+
+
 def _transposed_times(csr, num_wires, d_vec, stream):
     """M^T v on the device for one R1CS matrix M (m x W, CSR on the host) and a device vector v of m elements: the per-wire sums
     sum_k M[k][i] v[k].  The transpose is a stable sort of the entries by column (torch index work; the values keep their limb
     form).  zk_fr_spmv_dev gives a row to ONE thread, and a wire such as `one` may sit in every constraint -- a row of 2^20 entries
-    took 0.7 s -- so rows are cut into runs of at most SPLIT entries (first product: one partial sum per run) which a second,
-    all-ones matrix adds up per wire (runs of one wire are consecutive; up to SPLIT^2 = 2^20 entries per wire in two levels)."""
+    took 0.7 s -- so the entries of a wire are cut into runs of at most SPLIT (first product: one partial sum per run), and all-ones
+    matrices then add the partial sums up, again at most SPLIT per thread, level by level until one sum per wire is left."""
     import torch
     from ..device import fr_spmv
     row_ptr, col, vals = csr
@@ -53,28 +68,81 @@ def _transposed_times(csr, num_wires, d_vec, stream):
     counts = torch.from_numpy(np.diff(row_ptr.astype(np.int64))).to(dev)
     d_row = torch.repeat_interleave(torch.arange(m, device=dev), counts)
     order = torch.sort(d_col, stable=True).indices
-    lens = torch.bincount(d_col, minlength=num_wires)
-    if int(lens.max()) > SPLIT * SPLIT:
-        raise ValueError("a wire in more than %d constraints needs a third level here" % (SPLIT * SPLIT))
-    starts = torch.cumsum(lens, 0) - lens                                  # first entry of every wire
-    runs = (lens + SPLIT - 1) // SPLIT                                     # runs per wire (0 for a wire that appears nowhere)
-    run_first = torch.cumsum(runs, 0) - runs
-    n_runs = int(runs.sum())
-    wire_of_run = torch.repeat_interleave(torch.arange(num_wires, device=dev), runs)
-    ptr1 = torch.empty(n_runs + 1, dtype=torch.int64, device=dev)
-    ptr1[:n_runs] = starts[wire_of_run] + SPLIT * (torch.arange(n_runs, device=dev) - run_first[wire_of_run])
-    ptr1[n_runs] = d_col.shape[0]
-    ptr2 = torch.zeros(num_wires + 1, dtype=torch.int64, device=dev)
-    ptr2[1:] = torch.cumsum(runs, 0)
     i32 = lambda t: t.to(torch.int32).contiguous()
-    ptr1, col1, val1 = i32(ptr1), i32(d_row[order]), _dev(vals)[order].contiguous()
-    ptr2, col2 = i32(ptr2), i32(torch.arange(n_runs, device=dev))
-    val2 = torch.tensor([1, 0, 0, 0], dtype=torch.int64, device=dev).repeat(max(n_runs, 1), 1)
-    partial = torch.empty((max(n_runs, 1), 4), dtype=torch.int64, device=dev)
-    out = torch.empty((num_wires, 4), dtype=torch.int64, device=dev)
-    fr_spmv(ptr1.data_ptr(), col1.data_ptr(), val1.data_ptr(), d_vec.data_ptr(), partial.data_ptr(), n_runs, stream)
-    fr_spmv(ptr2.data_ptr(), col2.data_ptr(), val2.data_ptr(), partial.data_ptr(), out.data_ptr(), num_wires, stream)
-    return out
+    new = lambda rows: torch.empty((max(rows, 1), 4), dtype=torch.int64, device=dev)
+    one_row = _dev(np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    lens = torch.bincount(d_col, minlength=num_wires)                      # entries per wire
+    ptr, groups = _run_pointers(lens)
+    n = ptr.shape[0] - 1
+    cur = new(n)
+    # (every operand is held in a name until the call has been issued: a temporary dropped while the argument list is still being
+    # built hands its block back to the allocator, and the next temporary of the same list may be given it)
+    p32, c32, v_t = i32(ptr), i32(d_row[order]), _dev(vals)[order].contiguous()
+    fr_spmv(p32.data_ptr(), c32.data_ptr(), v_t.data_ptr(), d_vec.data_ptr(), cur.data_ptr(), n, stream)
+    while True:                                                            # cur: n partial sums, groups[i] consecutive ones per wire
+        last = int(groups.max()) <= SPLIT
+        if last:
+            ptr = torch.zeros(num_wires + 1, dtype=torch.int64, device=dev)
+            ptr[1:] = torch.cumsum(groups, 0)
+            rows = num_wires
+        else:
+            ptr, groups = _run_pointers(groups)
+            rows = ptr.shape[0] - 1
+        nxt = new(rows)
+        p32, c32, v_t = i32(ptr), i32(torch.arange(n, device=dev)), one_row.repeat(max(n, 1), 1)
+        fr_spmv(p32.data_ptr(), c32.data_ptr(), v_t.data_ptr(), cur.data_ptr(), nxt.data_ptr(), rows, stream)
+        cur, n = nxt, rows
+        if last:
+            return cur
+
+
+def crs_exponents(circuit, alpha, beta, delta, x, stream):
+    """The discrete logarithms of the CRS queries (zkp/groth16/setup.py:18-60 over the roots-of-unity QAP) as DEVICE vectors,
+    produced by the F_r vector kernels and never visiting the host:
+        w^k                       zk_fr_scale_powers_dev on a vector of ones
+        1 / (x - w^k)             prefix and suffix product scans (zk_fr_scan_dev) and ONE host inversion of the total
+        L_k(x)                    (x^m - 1) / m * w^k / (x - w^k)
+        A_i(x), B_i(x), C_i(x)    the TRANSPOSED sparse R1CS matrices times L (zk_fr_spmv_dev, _transposed_times)
+        lq[i]                     (beta A_i + alpha B_i + C_i)(x) / delta, zero at the public wires (setup.py:42-54)
+        powers[j] = x^j,  hq[k] = x^k Z(x) / delta for k < m - 1 and 0 for k = m - 1 (setup.py:18-23, 56-60, 65-69)
+    -> dict(powers (m, 4), lq (W, 4), hq (m, 4), qap {"A" | "B" | "C": (W, 4)}, Zx)."""
+    import torch
+    m, W = circuit.m, circuit.num_wires
+    zx = (pow(x, m, R) - 1) % R
+    if zx == 0 or delta == 0:
+        raise ValueError("the toxic x must lie outside the evaluation domain and delta must be non-zero")
+    dinv = pow(delta, -1, R)
+    fv = FrVec()
+    new = lambda rows: torch.empty((rows, 4), dtype=torch.int64, device="cuda")
+    one_row = _dev(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    ones = one_row.repeat(m, 1)
+    roots = ones.clone()
+    fv.scale_powers(roots.data_ptr(), m, pow(5, (R - 1) // m, R), stream)             # w^k
+    # 1 / (x - w^k) for all k: pre[k] = prod_{j<k} d_j, suf[k] = prod_{j>=k} d_j, inverse = pre[k] * suf[k+1] / total
+    pre, suf = new(m + 1), new(m + 1)
+    pre[0] = one_row
+    suf[m] = one_row
+    FrVec.lincomb(pre[1:].data_ptr(), [roots.data_ptr()], [R - 1], m, constant=x, stream=stream)      # d_k = x - w^k
+    suf[:m].copy_(pre[1:])
+    fv.scan(pre[1:].data_ptr(), m, product=True, reverse=False, stream=stream)
+    fv.scan(suf.data_ptr(), m, product=True, reverse=True, stream=stream)
+    total = _lib.limbs_to_ints(pre[m:m + 1].cpu().numpy().view(np.uint64))[0]
+    lag = new(m)
+    FrVec.mul(lag.data_ptr(), pre.data_ptr(), suf[1:].data_ptr(), m, stream)
+    FrVec.mul(lag.data_ptr(), lag.data_ptr(), roots.data_ptr(), m, stream)
+    FrVec.lincomb(lag.data_ptr(), [lag.data_ptr()], [zx * pow(m, -1, R) % R * pow(total, -1, R) % R], m, stream=stream)   # L_k(x)
+    qap = {name: _transposed_times(csr, W, lag, stream) for name, csr in circuit.r1cs_csr().items()}   # M_i(x) = sum_k M[k][i] L_k(x)
+    lq = new(W)
+    FrVec.lincomb(lq.data_ptr(), [qap[k].data_ptr() for k in "ABC"], [beta * dinv % R, alpha * dinv % R, dinv], W, stream=stream)
+    lq[torch.from_numpy(np.array(circuit.pub, dtype=np.int64)).cuda()] = 0
+    powers = ones
+    fv.scale_powers(powers.data_ptr(), m, x, stream)
+    hq = torch.zeros((m, 4), dtype=torch.int64, device="cuda")
+    if m > 1:
+        FrVec.lincomb(hq.data_ptr(), [powers.data_ptr()], [zx * dinv % R], m - 1, stream=stream)
+    torch.cuda.synchronize()
+    fv.close()
+    return dict(powers=powers, lq=lq, hq=hq, qap=qap, Zx=zx)
 
 
 class ScaleCRS:
@@ -82,14 +150,8 @@ class ScaleCRS:
 
     The reference evaluates every wire polynomial at the toxic x with Python loops and multiplies G by each exponent in turn;
     at 2^20 constraints that shape costs seconds of interpreter time around kernels that take milliseconds.  Here the exponents
-    are produced by the F_r vector kernels and never visit the host:
-        w^k                       zk_fr_scale_powers_dev on a vector of ones
-        1 / (x - w^k)             prefix and suffix product scans (zk_fr_scan_dev) and ONE host inversion of the total
-        L_k(x)                    (x^m - 1) / m * w^k / (x - w^k)
-        A_i(x), B_i(x), C_i(x)    the TRANSPOSED sparse R1CS matrices times L (zk_fr_spmv_dev)
-        L query exponents         (beta A_i + alpha B_i + C_i)(x) / delta       (zk_fr_lincomb_dev; zero at the public wires)
-        x^j, x^k Z(x) / delta     zk_fr_scale_powers_dev, zk_fr_lincomb_dev
-    and the points by the fixed-base batch kernels on device buffers (zk_fixed_base_g1_dev / _g2_dev)."""
+    come from crs_exponents (F_r vector kernels) and the points from the fixed-base batch kernels on device buffers
+    (zk_fixed_base_g1_dev / _g2_dev): 0.1 s for 2^20 constraints where the Python loops took 3.5 s."""
 
     def __init__(self, circuit, alpha, beta, gamma, delta, x_val):
         import torch
@@ -97,47 +159,10 @@ class ScaleCRS:
         m, W = circuit.m, circuit.num_wires
         al, be, ga, de, x = (v % R for v in (alpha, beta, gamma, delta, x_val))
         self.toxic = dict(alpha=al, beta=be, gamma=ga, delta=de, x=x)
-        zx = (pow(x, m, R) - 1) % R
-        if zx == 0 or de == 0:
-            raise ValueError("ScaleCRS: x must lie outside the evaluation domain and delta must be non-zero")
-        self.Zx = zx
-        dinv = pow(de, -1, R)
         lib = _lib.load()
         st = torch.cuda.current_stream().cuda_stream
-        fv = FrVec()
-        new = lambda rows: torch.empty((rows, 4), dtype=torch.int64, device="cuda")
-        one_row = _dev(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
-        ones = one_row.repeat(m, 1)
-        omega = pow(5, (R - 1) // m, R)
-        roots = ones.clone()
-        fv.scale_powers(roots.data_ptr(), m, omega, st)                                   # w^k
-        # 1 / (x - w^k) for all k: pre[k] = prod_{j<k} d_j, suf[k] = prod_{j>=k} d_j, inverse = pre[k] * suf[k+1] / total
-        pre, suf = new(m + 1), new(m + 1)
-        pre[0] = one_row
-        suf[m] = one_row
-        FrVec.lincomb(pre[1:].data_ptr(), [roots.data_ptr()], [R - 1], m, constant=x, stream=st)      # d_k = x - w^k
-        suf[:m].copy_(pre[1:])
-        fv.scan(pre[1:].data_ptr(), m, product=True, reverse=False, stream=st)
-        fv.scan(suf.data_ptr(), m, product=True, reverse=True, stream=st)
-        total = _lib.limbs_to_ints(pre[m:m + 1].cpu().numpy().view(np.uint64))[0]
-        lag = new(m)
-        FrVec.mul(lag.data_ptr(), pre.data_ptr(), suf[1:].data_ptr(), m, st)
-        FrVec.mul(lag.data_ptr(), lag.data_ptr(), roots.data_ptr(), m, st)
-        FrVec.lincomb(lag.data_ptr(), [lag.data_ptr()], [zx * pow(m, -1, R) % R * pow(total, -1, R) % R], m, stream=st)   # L_k(x)
-        # per-wire QAP values: M_i(x) = sum_k M[k][i] L_k(x)
-        self.d_qap = {}
-        for name, csr in circuit.r1cs_csr().items():
-            self.d_qap[name] = _transposed_times(csr, W, lag, st)
-        # exponents of the L query (private wires; zero, i.e. the placeholder / infinity, at the public ones: setup.py:42-54)
-        lq = new(W)
-        FrVec.lincomb(lq.data_ptr(), [self.d_qap[k].data_ptr() for k in "ABC"], [be * dinv % R, al * dinv % R, dinv], W, stream=st)
-        lq[torch.from_numpy(np.array(circuit.pub, dtype=np.int64)).cuda()] = 0
-        self.d_l_scalars = lq
-        powers = ones                                                                     # x^j  (setup.py:18-23, 65-69)
-        fv.scale_powers(powers.data_ptr(), m, x, st)
-        hq = new(m - 1) if m > 1 else None                                                # x^k Z(x) / delta, k < m - 1  (setup.py:56-60)
-        if m > 1:
-            FrVec.lincomb(hq.data_ptr(), [powers.data_ptr()], [zx * dinv % R], m - 1, stream=st)
+        ex = crs_exponents(circuit, al, be, de, x, st)
+        self.Zx, self.d_qap, self.d_l_scalars = ex["Zx"], ex["qap"], ex["lq"]
         # sigma1_1 / sigma2_1 (setup.py:15-16, 62-63)
         self.sigma1_1 = fixed_base_mul(G1, [al, be, de])
         self.sigma2_1 = fixed_base_mul(G2, [be, ga, de])
@@ -148,15 +173,14 @@ class ScaleCRS:
         self.d_s22 = torch.empty((m + 2, 16), dtype=torch.int64, device="cuda")
         self.d_s14 = torch.empty((W, 8), dtype=torch.int64, device="cuda")
         self.d_s15 = torch.empty((max(m - 1, 0), 8), dtype=torch.int64, device="cuda")
-        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), powers.data_ptr(), m, self.d_s12.data_ptr(), st))
-        _lib.check(lib.zk_fixed_base_g2_dev(_lib.ptr(g2), powers.data_ptr(), m, self.d_s22.data_ptr(), st))
-        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), lq.data_ptr(), W, self.d_s14.data_ptr(), st))   # exponent 0 -> infinity (zeros)
+        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), ex["powers"].data_ptr(), m, self.d_s12.data_ptr(), st))
+        _lib.check(lib.zk_fixed_base_g2_dev(_lib.ptr(g2), ex["powers"].data_ptr(), m, self.d_s22.data_ptr(), st))
+        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), ex["lq"].data_ptr(), W, self.d_s14.data_ptr(), st))   # exponent 0 -> infinity (zeros)
         if m > 1:
-            _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), hq.data_ptr(), m - 1, self.d_s15.data_ptr(), st))
+            _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), ex["hq"].data_ptr(), m - 1, self.d_s15.data_ptr(), st))
         self.d_s12[m:] = _dev(g1_to_limbs([self.sigma1_1[0], self.sigma1_1[2], self.sigma1_1[1]]))
         self.d_s22[m:] = _dev(g2_to_limbs([self.sigma2_1[0], self.sigma2_1[2]]))
         torch.cuda.synchronize()
-        fv.close()
 
 
 class ScaleProver:

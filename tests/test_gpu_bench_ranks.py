@@ -56,6 +56,8 @@ def test_four_rank_rehearsal_of_the_sharded_2pow26_msm_and_the_distributed_ntt()
                  "--cpu-sample", "128", "--ntt-log-n", "18")
     assert rec["n_gpus"] == 4 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert "REHEARSAL" in rec["config"]["collectives"]
+    seen = rec["config"]["ranks_seen"]                                   # four ranks, ONE physical device: the line says so itself
+    assert seen["ranks"] == 4 and seen["distinct_devices"] == 1 and sorted(r["rank"] for r in seen["by_rank"]) == [0, 1, 2, 3]
     extra = rec["extra"]
     assert extra["verified_closed_form"] is True
     one = extra["sharded_one_msm"]
@@ -71,6 +73,7 @@ def test_one_rank_over_rccl_takes_the_multi_rank_path():
                  "--cpu-sample", "128", "--ntt-log-n", "18", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-bound", "--no-witness-like")
     assert rec["n_gpus"] == 1 and rec["steps"] == 5
     assert rec["config"]["collectives"].startswith("RCCL")
+    assert rec["config"]["ranks_seen"]["ranks"] == 1 and rec["config"]["ranks_seen"]["distinct_devices"] == 1
     extra = rec["extra"]
     assert extra["verified_closed_form"] is True
     assert extra["sharded_one_msm"]["verified_closed_form"] is True

@@ -92,6 +92,17 @@ def test_scale_prover_closed_form(kind, log_m):
         assert hc[:len(q)] == q
 
 
+def test_setup_with_many_levels_of_run_splitting(monkeypatch):
+    """A wire that sits in every constraint (`one` in the chain circuit's C matrix) is summed level by level in runs of at most
+    SPLIT entries per thread (prover_ntt._transposed_times); with SPLIT = 4 a 2^10-constraint circuit takes five levels, what a
+    2^22-constraint one takes two of at the real SPLIT.  Every element of every query against the oracle."""
+    from zkhip.groth16 import prover_ntt
+    monkeypatch.setattr(prover_ntt, "SPLIT", 4)
+    for circ in (ChainCircuit(10, seed=9), BoolChainCircuit(10, seed=9)):
+        x_val = 3721 + (1 << 199)
+        _check_crs_against_oracle(ScaleCRS(circ, x_val=x_val, **TOXIC), x_val)
+
+
 def test_scale_prover_on_a_side_stream():
     """prove(..., stream=s) with s different from torch's current stream: the torch copies inside the prover and the backend's
     kernels must be ordered on s (they used to run on two streams).  The inputs are produced on s right before the call, so

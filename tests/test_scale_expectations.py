@@ -92,3 +92,15 @@ def test_csr_limbs_are_canonical():
             assert row_ptr.dtype == np.uint32 and col.dtype == np.uint32 and vals.dtype == np.uint64
             assert row_ptr[0] == 0 and row_ptr[-1] == col.shape[0] == vals.shape[0]
             assert all(0 <= v < R for v in co.from_limbs(vals)) and int(col.max()) < circ.num_wires
+
+
+def test_row_subset_of_a_csr_matrix():
+    """zkhip.groth16.prover_dist._rows_subset (the constraint rows a rank owns, in block-cyclic order) against dense indexing."""
+    from zkhip.groth16.prover_dist import _rows_subset
+    circ = BoolChainCircuit(5, seed=2)
+    m, W = circ.m, circ.num_wires
+    rows = (np.arange(8, 16)[:, None] + 16 * np.arange(2)[None, :]).reshape(-1) % m      # a BC-style pick, repeated rows allowed
+    for name, csr in circ.r1cs_csr().items():
+        sub = _rows_subset(csr, rows.astype(np.int64))
+        full = _dense(csr, m, W)
+        assert _dense(sub, rows.shape[0], W) == [full[int(k)] for k in rows], name
