@@ -10,9 +10,11 @@
 // pass.  Inside a tile the decimation-in-frequency butterflies run two stages at a time on 4
 // elements held in registers (one LDS round trip per two stages; three workgroups per CU).  Element VALUES are never
 // converted to Montgomery form: only the twiddles are (mont_mul(x, w*R) = x*w); elements are
-// kept as lazy 9x29-bit limbs (< 2r) in LDS and in the scratch buffer between passes, and are
-// canonical 32-byte words only at the first load and the last store.
-// HBM traffic: 64..72 bytes per element per pass; the kernel is bound by the vector-ALU issue rate (~10.5 modular
+// kept as lazy 9x29-bit limbs (< 2r) in LDS; in the scratch buffer between passes they travel as 8 words (a value below 2r fits
+// 255 bits), so that four adjacent elements are exactly one aligned 128-byte line (round 4: the 36-byte limb image made 144-byte
+// runs that straddle lines -- 2^22: 0.510 -> 0.495 ms, 2^24: 2.17 -> 2.12 ms in same-session A/B runs, although the pass kernels are
+// issue-bound and the repacking adds instructions); canonical (< r) only at the first load and the last store.
+// HBM traffic: 64 bytes per element per pass; the kernel is bound by the vector-ALU issue rate (~10.5 modular
 // products per element: butterflies + one per pass boundary, and 22 modular additions / subtractions), not by bandwidth.
 #include <string.h>
 #include "common.h"
@@ -144,7 +146,7 @@ __device__ __forceinline__ Fr io_coset(const NttIoArgs &io, uint32_t i) {
 }
 
 // One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
-// passes (lazy 9-limb form, 36 B); only the first load and the last store use the canonical
+// passes (9-limb form in LDS, 8 words = 32 B in the scratch); only the first load and the last store use the canonical
 // 32-byte encoding.  LDS: data[9][tile] (limb-major, slots swizzled: swz) | tw[9][2^lp]: the twiddles of stage s,
 // w^(j << (lp - 1 - s)) for j < 2^s, sit at 2^s + j, so that the lanes of a wavefront read neighbouring words at every stage
 // (one table of w^i indexed i = j << (lp - 1 - s) puts the late stages' few distinct twiddles all on one bank).
@@ -169,8 +171,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     uint32_t *tw = lds + NL * tile;
     // blockIdx.y = index of the transform (of the group of 2^gb transforms) inside a batch of independent transforms
     const uint32_t bbase = blockIdx.y << gb;
-    const uint32_t *in_c = static_cast<const uint32_t *>(in_v);
-    const Fr *in_l = static_cast<const Fr *>(in_v);
+    const uint32_t *in_c = static_cast<const uint32_t *>(in_v);   // canonical input or the 8-word scratch: both 32 bytes per element
 
     for (uint32_t i = t + 1; i < ntw; i += NTT_NT) {
         const uint32_t st = 31u - (uint32_t)__clz((int)i), j = i - (1u << st);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
                     if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
                 }
             } else {
-                v = in_l[((size_t)b << P.L) + i];
+                v = ld_canon(in_c + (((size_t)b << P.L) + i) * 8);   // 32-byte scratch: 8 words, value < 2r
             }
             lds_st(data, tile, swz(e), v);
         }
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
                     if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
                 }
             } else {
-                v = in_l[((size_t)b << P.L) + i];
+                v = ld_canon(in_c + (((size_t)b << P.L) + i) * 8);   // 32-byte scratch: 8 words, value < 2r
             }
             lds_st(data, tile, swz((j << g) | c), v);
         }
@@ -248,7 +249,6 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     }
 
     if (!FINAL) {
-        Fr *out_l = static_cast<Fr *>(out_v);
         const uint32_t sh = P.L - lp - P.sp;
         for (uint32_t e = t; e < tile; e += NTT_NT) {   // in LDS order: the digit comes out bit-reversed, k = brev(position)
             // the scratch runs along the element index: those bits fastest (with gb == 0 this is the LDS order itself)
@@ -261,7 +261,13 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             // two-level table with one extra multiplication
             const Fr w = P.direct_tw ? twA[((size_t)k << P.sp) + rem] : fe_mul(twA[ex & ((1u << P.lh) - 1u)], twB[ex >> P.lh]);  // < 2r
             x = fe_mul(x, w);                                                      // 2 * 2 < 169  ->  < 2r
-            out_l[((size_t)(bbase + cb) << P.L) + base_addr + ((size_t)k << P.sp) + ca] = x;
+            {
+                uint32_t w8[8];
+                fe_to_words(x, w8);
+                uint4 *q4 = reinterpret_cast<uint4 *>(static_cast<uint32_t *>(out_v) + (((size_t)(bbase + cb) << P.L) + base_addr + ((size_t)k << P.sp) + ca) * 8);
+                q4[0] = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+                q4[1] = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+            }
         }
     } else {
         uint32_t *out_c = static_cast<uint32_t *>(out_v);
@@ -386,7 +392,7 @@ NttPlan::NttPlan(unsigned log_n) : L_(log_n) {
     for (uint32_t d : digits_) lmax_ = std::max(lmax_, d);
     lh_ = (L_ + 1) / 2;
     build_tables();
-    // the inter-pass scratch (n * 36 bytes per transform in flight) is allocated by the first run()
+    // the inter-pass scratch (n * 32 bytes per transform in flight) is allocated by the first run()
     // per device: the opt-in to more than 64 KiB of dynamic LDS belongs to the function ON the current device
     static bool attr_done_dev[64] = {};
     ZK_HIP(hipGetDevice(&device_));
@@ -549,9 +555,9 @@ void NttPlan::launch_passes(const void *d_in, void *d_out, bool inverse, unsigne
                             hipStream_t st) {
     const size_t n = (size_t)1 << L_;
     if (batch > 65535) throw std::runtime_error("zk_ntt: batch must be <= 65535");
-    if (digits_.size() > 1 && tmp_.bytes < (size_t)batch * n * sizeof(Fr)) {
+    if (digits_.size() > 1 && tmp_.bytes < (size_t)batch * n * 32) {
         ZK_HIP(hipStreamSynchronize(st));  // the old scratch may still be in use
-        tmp_.alloc((size_t)batch * n * sizeof(Fr));
+        tmp_.alloc((size_t)batch * n * 32);
     }
     const int dir = inverse ? 1 : 0;
     const unsigned D = (unsigned)digits_.size();
