@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--no-witness-like", action="store_true", help="skip the secondary skewed-scalar run (keeps a profiler's per-kernel averages to the headline workload)")
     ap.add_argument("--shard-total-log", type=int, default=26, help="N > 1 only: log2 points of the secondary ONE-MSM-sharded-over-all-GPUs "
                     "measurement (BASELINE.json configs[4]; 0 = skip)")
+    ap.add_argument("--dist-groth16-log-m", type=int, default=20, help="N > 1 only (power-of-two N): log2 constraints of the Groth16 proof with every vector "
+                    "distributed over the ranks (0 = skip)")
     ap.add_argument("--dist-ntt-log-n", type=int, default=24, help="N > 1 only: log2 size of the single NTT spread over all GPUs (0 = skip)")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-GPU code path (process group, all-gather, fold) even with one rank")
     ap.add_argument("--no-rewarm", action="store_true", help="N > 1: no untimed steps between the opening barrier and the start of the clock")
@@ -675,6 +677,48 @@ def main():
             else:
                 extra["dist_ntt"] = {"error": "setup failed on some rank"}
             del x0, dn
+
+    # ---- secondary, N > 1 (or --force-dist): Groth16 prove() with every vector distributed over the ranks (zkhip.groth16.prover_dist:
+    # the rank's constraint rows, one all-to-all per transform, the rank's slice of every query, one all-gather of the partial sums)
+    if dist_on and args.dist_groth16_log_m and (world & (world - 1)) == 0:
+        dg = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_groth16
+            from zkhip.groth16.prover_dist import DistScaleCRS, DistScaleProver
+            from zkhip.groth16.prover_ntt import ChainCircuit
+            circ = ChainCircuit(args.dist_groth16_log_m, seed=7)
+            wit = circ.witness()[0]
+            toxic = dict(alpha=3926, beta=3604, gamma=2971, delta=1357, x=3721 + (1 << 201))
+            tg0 = time.perf_counter()
+            dcrs = DistScaleCRS(circ, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["x"])
+            t_dsetup = time.perf_counter() - tg0
+            dg = DistScaleProver(dcrs, device=cdev)
+            d_wit = torch.from_numpy(_lib.ints_to_limbs(wit).view(np.int64)).to(dev)
+        except Exception as exc:  # noqa: BLE001 -- agree first: no rank may wait alone in a collective
+            dg = None
+            sys.stderr.write("dist_groth16 set-up failed on rank %d: %r\n" % (rank, exc))
+        ready = torch.tensor([1.0 if dg is not None else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if float(ready.item()) == 1.0:
+            proof = dg.prove(d_wit, 4106, 4565)
+            fence()
+            tms = []
+            for _ in range(4):
+                tg0 = time.perf_counter()
+                proof = dg.prove(d_wit, 4106, 4565)
+                fence()
+                tms.append((time.perf_counter() - tg0) * 1e3)
+            tt = torch.tensor([min(tms)], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                extra["dist_groth16"] = {"log_m": args.dist_groth16_log_m, "prove_ms": round(float(tt.item()), 3), "prove_ms_all_rank0": [round(v, 3) for v in tms],
+                                         "setup_s_per_rank": round(t_dsetup, 3), "coefficients_per_rank": dcrs.cn, "g1_bases_per_rank": dcrs.n_g1,
+                                         "verified_closed_form": bool(bench_groth16.proof_equals_oracle(circ, toxic, wit, 4106, 4565, proof))}
+            del dg, dcrs, d_wit
+            torch.cuda.empty_cache()
+        else:
+            extra["dist_groth16"] = {"error": "setup failed on some rank"}
 
     # ---- secondary: "witness-like" scalars: half the scalars are 0 or 1, the rest uniform
     if rank == 0 and world == 1 and not args.no_witness_like:

@@ -53,7 +53,7 @@ def _check_roofline_and_cpu(rec):
 
 def test_four_rank_rehearsal_of_the_sharded_2pow26_msm_and_the_distributed_ntt():
     rec = _bench("--gpus", "4", "--rehearse", "--steps", "2", "--warmup", "1", "--shard-total-log", "26", "--dist-ntt-log-n", "24",
-                 "--cpu-sample", "128", "--ntt-log-n", "18")
+                 "--cpu-sample", "128", "--ntt-log-n", "18", "--dist-groth16-log-m", "16")
     assert rec["n_gpus"] == 4 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert "REHEARSAL" in rec["config"]["collectives"]
     seen = rec["config"]["ranks_seen"]                                   # four ranks, ONE physical device: the line says so itself
@@ -64,13 +64,16 @@ def test_four_rank_rehearsal_of_the_sharded_2pow26_msm_and_the_distributed_ntt()
     assert one["log_n_total"] == 26 and one["points_per_gpu"] == 1 << 24 and one["verified_closed_form"] is True
     dn = extra["dist_ntt"]
     assert dn["log_n"] == 24 and dn["roundtrip_exact"] is True
+    dg = extra["dist_groth16"]                                           # the proof with every vector spread over the four ranks
+    assert dg["log_m"] == 16 and dg["verified_closed_form"] is True and dg["coefficients_per_rank"] == 1 << 14
     assert extra["ntt"]["roundtrip_exact"] is True and "all_gpus" in extra["ntt"]
     _check_roofline_and_cpu(rec)
 
 
 def test_one_rank_over_rccl_takes_the_multi_rank_path():
     rec = _bench("--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--shard-total-log", "22", "--dist-ntt-log-n", "22",
-                 "--cpu-sample", "128", "--ntt-log-n", "18", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-bound", "--no-witness-like")
+                 "--cpu-sample", "128", "--ntt-log-n", "18", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-bound", "--no-witness-like",
+                 "--dist-groth16-log-m", "18")
     assert rec["n_gpus"] == 1 and rec["steps"] == 5
     assert rec["config"]["collectives"].startswith("RCCL")
     assert rec["config"]["ranks_seen"]["ranks"] == 1 and rec["config"]["ranks_seen"]["distinct_devices"] == 1
@@ -78,4 +81,5 @@ def test_one_rank_over_rccl_takes_the_multi_rank_path():
     assert extra["verified_closed_form"] is True
     assert extra["sharded_one_msm"]["verified_closed_form"] is True
     assert extra["dist_ntt"]["roundtrip_exact"] is True
+    assert extra["dist_groth16"]["verified_closed_form"] is True and extra["dist_groth16"]["coefficients_per_rank"] == 1 << 18
     _check_roofline_and_cpu(rec)
