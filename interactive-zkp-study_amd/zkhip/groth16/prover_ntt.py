@@ -200,6 +200,7 @@ class ScaleProver:
         self.off14, self.off15 = self.m + 3, self.m + 3 + self.W
         self.n_c = self.off15 + self.m - 1                     # all three queries behind each other: (m+3) + W + (m-1) bases
         self.g1 = MsmPlan(_lib.GROUP_G1, self.n_c if self.bound else max(self.W, self.m + 3), chunk_log=chunk_log)
+        self.a_chunked = self.m + 3 > (1 << (chunk_log or 22))
         self.g2 = MsmPlan(_lib.GROUP_G2, self.m + 2)
         if self.bound:
             st0 = torch.cuda.current_stream().cuda_stream
@@ -295,9 +296,13 @@ class ScaleProver:
         t_b2 = self._msm(self.g2, self.ext_b2, crs.d_s22, 0, m + 2, st)                  # beta + B(x) + s*delta in G2
         t_a = self._msm(self.g1, self.ext_a, crs.d_s12, 0, m + 3, st)                    # alpha + A(x) + r*delta
         if self.bound:
+            # from 2^22 constraints on the A query (m + 3 bases) is itself more than one chunk, and a plan takes ONE chunked submission
+            # at a time: it is collected before the merged query goes in
+            proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a)) if self.a_chunked else None
             t_c = self.g1.submit_bound(sc.data_ptr(), 0, self.n_c, st)
             proof_b = self._pt(self.g2, self.g2.collect_limbs(t_b2))                     # proving.py:35-45
-            proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                      # proving.py:23-33
+            if not self.a_chunked:
+                proof_a = self._pt(self.g1, self.g1.collect_limbs(t_a))                  # proving.py:23-33
             proof_c = self._pt(self.g1, self.g1.collect_limbs(t_c))
             return proof_a, proof_b, proof_c, h
         t_b1 = self._msm(self.g1, self.ext_b1, crs.d_s12, 0, m + 3, st)                  # beta + B(x) in G1

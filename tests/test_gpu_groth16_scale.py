@@ -157,6 +157,13 @@ def test_scale_prover_2pow20_constraints_closed_form():
     chunked = ScaleProver(crs, chunk_log=21)
     chunked.load_r1cs(circ.r1cs_csr())
     assert (pa, pb, pc) == chunked.prove_from_witness(d_w, r, s)[:3]
+    # From 2^22 constraints on the A query itself (m + 3 bases) is chunked as well, and a plan holds one chunked submission at a
+    # time: the same with 2^20-point chunks (round 4: a 2^22-constraint proof failed with "a chunked submission is outstanding").
+    del chunked
+    torch.cuda.empty_cache()
+    chunked = ScaleProver(crs, chunk_log=20)
+    chunked.load_r1cs(circ.r1cs_csr())
+    assert chunked.a_chunked and (pa, pb, pc) == chunked.prove_from_witness(d_w, r, s)[:3]
 
 
 def _sharded_worker(rank, world, port, log_m, ret):
