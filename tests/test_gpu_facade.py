@@ -225,6 +225,29 @@ def test_srs_generate(srs_small, kzg_golden):
     assert len(s0.g1_powers) == 1 and s0.g1_powers[0] == G1
 
 
+def test_device_srs_equals_the_golden_string_and_the_oracle(kzg_golden):
+    """zkhip.plonk.srs.DeviceSRS: the same [tau^i]_1 (zkp/plonk/srs.py:68-85) with the exponents and the points produced on the
+    device -- the golden string of seed 42 at the reference's size, and at 5000 powers (the table kernel of the fixed-base batch)
+    against the oracle's tau^i * G1 and the host-buffer batch."""
+    import numpy as np
+    import c_oracle as co
+    from zkhip import _lib
+    from zkhip.field import g1_to_limbs
+    from zkhip.plonk.srs import DeviceSRS
+    d = DeviceSRS.generate(max_degree=8, seed=42).to_host()
+    assert d.g1_powers == [g1j(p) for p in kzg_golden["g1_powers"]] and d.g2_powers == [g2j(p) for p in kzg_golden["g2_powers"]]
+    tau = int(kzg_golden["tau"])
+    big = DeviceSRS.generate(max_degree=4999, tau=tau, keep_tau=True)
+    assert big.tau == tau and DeviceSRS.generate(max_degree=3, seed=42).tau is None       # the toxic value is not kept by default
+    pts = big.d_g1.cpu().numpy().view(np.uint64)
+    idx = [0, 1, 2, 2500, 4999]
+    assert np.array_equal(pts[idx], co.g1_fixed_base_arr(o.G1, co.to_limbs([pow(tau, i, o.R) for i in idx])))
+    powers = _lib.ints_to_limbs([pow(tau, i, o.R) for i in range(5000)])
+    host = np.zeros((5000, 8), dtype=np.uint64)
+    _lib.check(_lib.load().zk_fixed_base_g1(_lib.ptr(g1_to_limbs([G1])), _lib.ptr(powers), 5000, _lib.ptr(host)))
+    assert np.array_equal(pts, host)
+
+
 def test_commit_cases(srs_small, kzg_golden):
     for name, c in kzg_golden["commits"].items():
         poly = Polynomial([FR(int(v)) for v in c["coeffs"]])

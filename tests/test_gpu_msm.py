@@ -406,6 +406,38 @@ def test_fixed_base_batches_bit_exact(n):
     assert not out1.any()
 
 
+@pytest.mark.parametrize("n", [1, 7, 4095, 4096, 6001])
+def test_fixed_base_device_buffers_equal_host_buffers_and_oracle(n):
+    """zk_fixed_base_g1_dev / _g2_dev (key generation at scale: exponents and points stay in HBM; setup.py:18-69, srs.py:77-85):
+    the same points as the host-buffer batch -- both code paths (one double-and-add per thread below 4096 scalars, the byte-window
+    table from there on) -- and the oracle's k * P on a few of them, with edge exponents 0, 1, r - 1 and one above r."""
+    import torch
+    rng = np.random.default_rng(4000 + n)
+    K = rand_fr_limbs(rng, n)
+    for j, v in enumerate([0, 1, o.R - 1, (1 << 256) - 1][:n]):
+        K[j] = limb_row(v)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    dK = torch.from_numpy(K.view(np.int64)).cuda()
+    idx = sorted({0, min(1, n - 1), min(2, n - 1), min(3, n - 1), n // 2, n - 1})
+    base1 = co.g1_to_arr([co.g1_mul(o.G1, 11)])
+    host1, dev1 = np.zeros((n, 8), dtype=np.uint64), torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+    _lib.check(lib.zk_fixed_base_g1(_lib.ptr(base1), _lib.ptr(K), n, _lib.ptr(host1)))
+    _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(base1), dK.data_ptr(), n, dev1.data_ptr(), st))
+    got1 = dev1.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got1, host1)
+    assert np.array_equal(got1[idx], co.g1_fixed_base_arr(co.g1_from_arr(base1)[0], K[idx]))
+    base2 = co.g2_to_arr([o.G2])
+    host2, dev2 = np.zeros((n, 16), dtype=np.uint64), torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    _lib.check(lib.zk_fixed_base_g2(_lib.ptr(base2), _lib.ptr(K), n, _lib.ptr(host2)))
+    _lib.check(lib.zk_fixed_base_g2_dev(_lib.ptr(base2), dK.data_ptr(), n, dev2.data_ptr(), st))
+    got2 = dev2.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got2, host2)
+    assert np.array_equal(got2[idx], co.g2_fixed_base_arr(o.G2, K[idx]))
+    assert lib.zk_fixed_base_g1_dev(None, dK.data_ptr(), n, dev1.data_ptr(), st) == _lib.ZK_ERR_INVALID
+    assert lib.zk_fixed_base_g1_dev(_lib.ptr(base1), dK.data_ptr(), 0, dev1.data_ptr(), st) == 0      # n = 0: nothing to do
+
+
 def test_chunked_msm_small_chunks():
     """MSMs beyond the chunk size (2^24 points; here 2^12 through the test knob) run as consecutive chunks in the
     plan's lanes with the partial sums added on the host: blocking, pipelined and partial forms, bit-exact."""

@@ -9,6 +9,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "interactive-zkp-study_amd"))
 
 
+
+def committed_timeline(name):
+    """The summary line of the committed kernel timeline of one proof (profiles/*_<name>_timeline.txt, written from a
+    rocprofv3 --kernel-trace run by tools/trace_window.py): GPU-busy time and the sum of the kernel durations inside the proof's
+    window.  Quoted with its source, not measured by this run; None when no such file exists."""
+    import glob, re
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_timeline.txt" % name)))
+    if not found:
+        return None
+    m = None
+    for ln in open(found[-1]):
+        m = re.match(r"window ([0-9.]+) ms: busy ([0-9.]+) ms, idle ([0-9.]+) ms, kernel-time sum ([0-9.]+) ms", ln) or m
+    if not m:
+        return None
+    return {"source": os.path.relpath(found[-1], ROOT), "window_ms": float(m.group(1)), "gpu_busy_ms": float(m.group(2)),
+            "gpu_idle_ms": float(m.group(3)), "kernel_time_sum_ms": float(m.group(4)),
+            "note": "from a separate rocprofv3 --kernel-trace run of this tool (kernels of concurrent MSM lanes overlap, so the sum may exceed the window)"}
+
 def mulmod_limbs(vals):
     from zkhip import _lib
     return _lib.ints_to_limbs(vals)
@@ -19,6 +37,7 @@ def run(log_n, reps, profile=False):
     from zkhip import _lib
     from zkhip.field import CURVE_ORDER as R, G1, G2, fixed_base_mul, get_root_of_unity
     from zkhip.plonk.prover_device import DevicePlonk
+    from zkhip.plonk.srs import DeviceSRS
     from zkhip.plonk.verifier import verify
     n = 1 << log_n
     rng = np.random.default_rng(11)
@@ -52,14 +71,10 @@ def run(log_n, reps, profile=False):
         s3[:n - 1] = dom[1:]                                                                  # c_i  -> position of a_{i+1}: omega^(i+1)
         FrVec.lincomb(s3[n - 1:].data_ptr(), [dom[n - 1:].data_ptr()], [3], 1, stream=st)    # c_{n-1} -> itself
         sig = [s1, s2, s3]
-        # SRS: [tau^i]_1, the exponents by zk_fr_scale_powers_dev, the points by the fixed-base batch on device buffers (srs.py:77-85)
+        # SRS: [tau^i]_1 built on the device (zkhip.plonk.srs.DeviceSRS: srs.py:77-85 with both loops on the GPU)
         tau = 0xC0FFEE1234567
-        powers = ones
-        fv.scale_powers(powers.data_ptr(), n + 8, tau, st)
-        P = torch.empty((n + 8, 8), dtype=torch.int64, device="cuda")
-        g1 = np.array([[1, 0, 0, 0, 2, 0, 0, 0]], dtype=np.uint64)
-        _lib.check(lib.zk_fixed_base_g1_dev(_lib.ptr(g1), powers.data_ptr(), n + 8, P.data_ptr(), st))
         fv.close()
+        P = DeviceSRS.generate(n + 7, tau=tau).d_g1
         dev = DevicePlonk(sel, sig, P)
         return dev, tau
 
@@ -105,7 +120,7 @@ def run(log_n, reps, profile=False):
     mismatches = dev.closed_form_mismatches(proof, tau)
     return {"commitments_equal_p_of_tau_times_G1": not mismatches, "commitment_mismatches": mismatches,
             "log_n": log_n, "gates": n, "prove_ms": round(min(times[1:]) * 1e3, 3), "prove_ms_all": [round(t * 1e3, 3) for t in times[1:]],
-            "first_call_ms": round(times[0] * 1e3, 3), "witness_gen_s_python": round(t_wit, 2), "preprocess_s": round(t_pre, 3), "preprocess_s_first_call_in_process": round(t_pre_first, 3), "verified": bool(ok)}
+            "first_call_ms": round(times[0] * 1e3, 3), "witness_gen_s_python": round(t_wit, 2), "preprocess_s": round(t_pre, 3), "preprocess_s_first_call_in_process": round(t_pre_first, 3), "verified": bool(ok), "kernel_trace_of_one_proof": committed_timeline("plonk")}
 
 
 if __name__ == "__main__":

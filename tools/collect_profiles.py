@@ -10,7 +10,7 @@ import argparse, csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SQ_COUNTERS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE"]
-BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--no-facade", "--sizes", "", "--sizes-ntt", ""]
+BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--no-g2", "--no-facade", "--sizes", "", "--sizes-ntt", ""]
 
 
 def sh(cmd, log):

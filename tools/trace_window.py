@@ -17,7 +17,7 @@ def main():
     f = sorted(glob.glob(os.path.join(a.dir, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 
     def short(n):
-        n = n.replace("void zk::", "").replace("zk::", "")
+        n = n.replace("(anonymous namespace)::", "").replace("void zk::", "").replace("zk::", "")
         g2 = "Fp2" in n
         n = re.sub(r"[<(].*", "", n).replace("_kernel", "").replace("msm_", "")
         return n + (":g2" if g2 else "")
