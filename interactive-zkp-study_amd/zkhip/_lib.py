@@ -110,6 +110,10 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        # The host-buffer entry points keep plans per thread (zk_cache_*); their C++ thread_local destructors would otherwise return
+        # device memory while the process is already tearing the HIP runtime down.  Drop the calling (main) thread's cache first.
+        import atexit
+        atexit.register(lambda: lib.zk_cache_clear())
     return _lib
 
 
