@@ -692,11 +692,12 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumul
 }
 // [accumulate-kernel-end]
 
-// A grid of workgroups that do nothing, launched between the accumulate kernel and the bucket reduction.  Measured, not understood
-// (profiles/r04_experiments.md): with the reduction's first kernel directly behind the accumulate kernel that kernel takes 25 % longer
-// (G1 0.28 instead of 0.22 ms, G2 0.87 instead of 0.70 ms for 2^20 points, blocking and in every A/B pair); a 1024-workgroup no-op
-// between the two restores it, a one-workgroup no-op does not, and an LDS reservation that pins the reduction to one wavefront per
-// SIMD does not either.  Until round 4 the (normally empty) heavy-bucket kernel sat there and did this by accident.
+// A grid of workgroups that do nothing, launched between the accumulate kernel and the bucket reduction (profiles/r04_experiments.md,
+// section 3): with the reduction's first kernel directly behind the accumulate kernel that kernel takes 25 % longer (G1 0.28 instead of
+// 0.22 ms, G2 0.87 instead of 0.70 ms for 2^20 points, in every A/B pair) -- its 1024 one-wavefront workgroups are then not spread one
+// per SIMD.  A pass of 1024 empty workgroups in between restores the spread (a one-workgroup no-op does not, an LDS reservation
+// does not); launching the reduction as 256 workgroups of four wavefronts avoids the penalty too, 3 % behind this form.  Until
+// round 4 the (normally empty) heavy-bucket kernel sat here and did this by accident.
 template <int DUMMY> __global__ void msm_boundary_kernel(const uint32_t *p) {
     if (p == nullptr && threadIdx.x == 999) __builtin_trap();   // never taken (p is the lane's error counter): keeps the body from being empty
 }
