@@ -104,3 +104,34 @@ def test_row_subset_of_a_csr_matrix():
         sub = _rows_subset(csr, rows.astype(np.int64))
         full = _dense(csr, m, W)
         assert _dense(sub, rows.shape[0], W) == [full[int(k)] for k in rows], name
+
+
+@pytest.mark.parametrize("split", [2, 4, 1024])
+def test_run_pointers_cut_groups_into_bounded_runs(monkeypatch, split):
+    """prover_ntt._run_pointers (host logic of the device key generation): groups of consecutive entries are cut into runs of at most
+    SPLIT entries; runs of one group stay consecutive, cover it exactly, and empty groups get no run -- applied repeatedly (the
+    levels of _transposed_times) every group ends up as one sum."""
+    import torch
+    from zkhip.groth16 import prover_ntt
+    monkeypatch.setattr(prover_ntt, "SPLIT", split)
+    rng = np.random.default_rng(split)
+    lens = torch.from_numpy(rng.integers(0, 40, size=50).astype(np.int64))
+    lens[7] = 0
+    lens[11] = 1000
+    vals = torch.arange(int(lens.sum()), dtype=torch.int64) % 97 + 1              # the "entries": sums are checked through all levels
+    want = [int(v.sum()) for v in torch.split(vals, [int(x) for x in lens])]
+    cur, groups, levels = vals, lens, 0
+    while True:
+        ptr, runs = prover_ntt._run_pointers(groups)
+        assert int(ptr[0]) == 0 and int(ptr[-1]) == cur.shape[0] and bool((ptr[1:] >= ptr[:-1]).all())
+        assert int((ptr[1:] - ptr[:-1]).max()) <= split and int(runs.sum()) == ptr.shape[0] - 1
+        assert bool((runs == (groups + split - 1) // split).all())
+        cur = torch.stack([cur[int(a):int(b)].sum() for a, b in zip(ptr[:-1], ptr[1:])]) if ptr.shape[0] > 1 else cur[:0]
+        groups, levels = runs, levels + 1
+        if int(groups.max()) <= 1:
+            break
+    got, pos = [], 0
+    for g in groups:
+        got.append(int(cur[pos]) if int(g) else 0)
+        pos += int(g)
+    assert got == want and levels >= (1 if split >= 1000 else 3)
