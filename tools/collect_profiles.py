@@ -13,6 +13,18 @@ SQ_COUNTERS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUS
 BENCH_QUICK = ["python3", "bench.py", "--cpu-sample", "0", "--groth16-log-m", "0", "--plonk-log-n", "0", "--no-witness-like", "--no-bound", "--no-g2", "--no-facade", "--sizes", "", "--sizes-ntt", ""]
 
 
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_hash", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    return bench
+
+
 def sh(cmd, log):
     with open(log, "w") as f:
         rc = subprocess.call(cmd, stdout=f, stderr=subprocess.STDOUT, cwd=ROOT)
@@ -24,6 +36,9 @@ def run(rnd):
     out = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     os.makedirs(out, exist_ok=True)
     env_tmp = os.environ.setdefault("TMPDIR", "/tmp")
+    # the arithmetic sources the counters of this run belong to: stamped NOW, on the tree that is being measured (fold only copies it)
+    with open(os.path.join(out, "arithmetic_source_sha256.json"), "w") as f:
+        json.dump({"arithmetic_source_sha256": _bench_module().arithmetic_source_hash()}, f)
     rc = sh(["python3", "bench.py"], os.path.join(out, "bench_line.log"))
     if rc:
         return rc
@@ -57,17 +72,14 @@ def fold_sq(src, dst, rnd):
     for k in acc:                                   # the headline workload's launches only: those with the kernel's largest grid
         top = max(grid[k].values())
         acc[k] = {i: v for i, v in acc[k].items() if grid[k][i] == top}
-    # the sources the counters belong to: bench.py quotes the issue rate only while they are unchanged
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench_for_hash", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    argv, sys.argv = sys.argv, ["bench.py"]
+    # the sources the counters belong to (stamped by `run` on the measured tree): bench.py quotes the issue rate only while they are
+    # unchanged; a collection without the stamp stays untagged, i.e. unquoted
     try:
-        spec.loader.exec_module(bench)
-    finally:
-        sys.argv = argv
+        tag = json.load(open(os.path.join(src, "arithmetic_source_sha256.json"))).get("arithmetic_source_sha256")
+    except (OSError, ValueError):
+        tag = None
     with open(os.path.join(dst, rnd + "_pmc_sq_summary.meta.json"), "w") as f:
-        json.dump({"arithmetic_source_sha256": bench.arithmetic_source_hash()}, f, indent=1)
+        json.dump({"arithmetic_source_sha256": tag}, f, indent=1)
     with open(os.path.join(dst, rnd + "_pmc_sq_summary.csv"), "w") as f:
         f.write("kernel,dispatches," + ",".join(SQ_COUNTERS) + ",valu_insts_per_simd_cycle,active_valu_frac_of_wave_cycles,wait_inst_frac_of_wave_cycles\n")
         for k, disp in sorted(acc.items(), key=lambda kv: -sum(d.get("SQ_BUSY_CYCLES", 0) for d in kv[1].values())):
@@ -138,9 +150,14 @@ def fold(rnd):
     acc_k = [k for k in per if k.startswith("msm_accumulate_kernel") and "FpTag" in k and "Fp2" not in k]
     if acc_k and len(per[acc_k[0]]) == 2:
         v = per[acc_k[0]]
-        traffic = {"msm_accumulate_g1_2^20": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0,
-                   "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from two separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_summary.csv); "
-                            "raw reading, no x2 FETCH correction (64-byte gathers, not a 16 B/lane streaming read)" % rnd}
+        # calibrated on this kernel's own access patterns (profiles/r04_fetch_calibration.md, tools/fetch_calibration.hip): the 64-byte point
+        # gathers are counted exactly (Infinity-Cache hits included), the 4-byte list words at one half -- W * n = 16 * 2^20 words per launch
+        list_half = 16 * (1 << 20) * 4 / 2.0
+        traffic = {"msm_accumulate_g1_2^20": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 + list_half,
+                   "raw_fetch_plus_write_bytes": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "list_words_counted_at_one_half_bytes_added": list_half,
+                   "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from two separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_summary.csv), "
+                            "corrected as calibrated in profiles/r04_fetch_calibration.md: 64-byte gathers read exactly (no x2; the guide's 1/2 holds for "
+                            "16 B/lane streaming reads), 4-byte list words read 1/2" % rnd}
         with open(os.path.join(dst, "traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     fold_sq(src, dst, rnd)
