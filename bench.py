@@ -594,6 +594,16 @@ def main():
         extra["ntt"] = {"log_n": L, "ms_per_transform": round(ms, 4), "elements_per_s": m / (ms * 1e-3),
                         "algorithmic_GBps": 64.0 * m / (ms * 1e-3) / 1e9, "hbm_frac": 64.0 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "roundtrip_exact": exact, "timed_round_trips": reps, "warmup_round_trips": 10}
+        # the same in the shape of the headline's roofline object (algorithmic bytes: 64 B per element and transform);
+        # traffic: the committed counter passes' raw FETCH + WRITE over the three pass kernels, for this size only
+        ntt_traffic = None
+        try:
+            ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("ntt_2^%d_per_transform_raw" % L)
+        except Exception:  # noqa: BLE001
+            pass
+        extra["ntt"]["roofline"] = {"bound": "hbm", "kernel": "ntt_pass_kernel (all passes of one transform)", "achieved": extra["ntt"]["algorithmic_GBps"],
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": extra["ntt"]["hbm_frac"], "traffic": ntt_traffic,
+                                    "note": "issue-bound (0.20-0.21 of 0.25 vector instructions per SIMD cycle: profiles/*_pmc_sq_summary.csv); ~160 instructions per element and stage"}
         if dist_on:
             agg = world * 2 * reps * m / span   # wall clock between barriers (includes launch latency), all ranks
             extra["ntt"]["all_gpus"] = {"mode": "one polynomial per GPU, no exchange", "elements_per_s": agg,

@@ -158,6 +158,13 @@ def fold(rnd):
                    "_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from two separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_summary.csv), "
                             "corrected as calibrated in profiles/r04_fetch_calibration.md: 64-byte gathers read exactly (no x2; the guide's 1/2 holds for "
                             "16 B/lane streaming reads), 4-byte list words read 1/2" % rnd}
+        # the NTT passes of the 2^22-point transform (the bench's secondary; the profiled run transforms forward and back, both
+        # directions use the same three kernels): FETCH + WRITE summed over the passes, RAW -- WRITE_SIZE is exact, the passes' loads
+        # (32-byte elements as two 16-byte loads per lane in 128-byte runs, 36-byte twiddles as dwords) are not calibrated
+        ntt = {k: v for k, v in per.items() if k.startswith("ntt_pass_kernel") and len(v) == 2}
+        if ntt:
+            traffic["ntt_2^22_per_transform_raw"] = sum(v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in ntt.values()) * 1024.0
+            traffic["ntt_2^22_per_pass_raw"] = {k: {"fetch": v["FETCH_SIZE"] * 1024.0, "write": v["WRITE_SIZE"] * 1024.0} for k, v in sorted(ntt.items())}
         with open(os.path.join(dst, "traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     fold_sq(src, dst, rnd)
