@@ -595,10 +595,11 @@ def main():
                         "algorithmic_GBps": 64.0 * m / (ms * 1e-3) / 1e9, "hbm_frac": 64.0 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "roundtrip_exact": exact, "timed_round_trips": reps, "warmup_round_trips": 10}
         # the same in the shape of the headline's roofline object (algorithmic bytes: 64 B per element and transform);
-        # traffic: the committed counter passes' raw FETCH + WRITE over the three pass kernels, for this size only
+        # traffic: the committed counter passes' FETCH + WRITE over the three pass kernels (16-byte loads corrected x2 as calibrated:
+        # profiles/r04_fetch_calibration.md), for this size only
         ntt_traffic = None
         try:
-            ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("ntt_2^%d_per_transform_raw" % L)
+            ntt_traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("ntt_2^%d_per_transform_corrected" % L)
         except Exception:  # noqa: BLE001
             pass
         extra["ntt"]["roofline"] = {"bound": "hbm", "kernel": "ntt_pass_kernel (all passes of one transform)", "achieved": extra["ntt"]["algorithmic_GBps"],
