@@ -320,6 +320,39 @@ class DistNtt:
         dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
         return recv
 
+    # natural order across ranks ------------------------------------------------------------------
+    # The block-cyclic layouts are what a prover's chain needs (transform -> pointwise -> inverse -> MSM never leaves them).  Where
+    # the NATURAL order is wanted across ranks -- rank r holding the contiguous slice [r n/R, (r+1) n/R) -- it is one more
+    # all-to-all of n/R^2 elements per pair and a local transpose ("output order must be fixed up to
+    # natural order"): BC(n1) stores X[k1 + n1 k2] at [k1 local][k2]; the natural slice of rank s is k2 in its n2/R block, all k1.
+    def bc_out_to_natural(self, y):
+        """(k, n2, 4) BC(n1) block (what forward() returns) -> (n/R, 4): this rank's contiguous slice of the natural order."""
+        R, k, c, n1 = self.world, self.k, self.c, self.n1
+        send = y.view(k, R, c, 4).permute(1, 0, 2, 3).contiguous()      # [s][k1 local][k2 local of s]
+        recv = self._exchange(send)                                     # [r][k1 local of r][k2 local]  ==  [k1][k2 local]
+        return recv.view(n1, c, 4).permute(1, 0, 2).contiguous().view(c * n1, 4)   # [k2 local][k1]: index k1 + n1 k2, k2 in this rank's block
+
+    def natural_to_bc_out(self, z):
+        """The inverse of bc_out_to_natural: (n/R, 4) contiguous slice -> (k, n2, 4) BC(n1) block (what inverse() takes)."""
+        R, k, c, n1, n2 = self.world, self.k, self.c, self.n1, self.n2
+        send = z.view(c, R, k, 4).permute(1, 2, 0, 3).contiguous()      # [s][k1 local of s][k2 local]
+        recv = self._exchange(send)                                     # [r][k1 local][k2 local of r]
+        return recv.permute(1, 0, 2, 3).contiguous().view(k, n2, 4)     # [k1 local][k2]
+
+    def natural_to_bc_in(self, z):
+        """(n/R, 4) contiguous slice of a natural-order vector x[j1 n2 + j2] -> (c, n1, 4) BC(n2) block (what forward() takes)."""
+        R, k, c, n1, n2 = self.world, self.k, self.c, self.n1, self.n2
+        send = z.view(k, R, c, 4).permute(1, 0, 2, 3).contiguous()      # rows j1 in this rank's block: [s][j1 local][j2 local of s]
+        recv = self._exchange(send)                                     # [r][j1 local of r][j2 local]  ==  [j1][j2 local]
+        return recv.view(n1, c, 4).permute(1, 0, 2).contiguous()        # [j2 local][j1]
+
+    def bc_in_to_natural(self, x):
+        """The inverse of natural_to_bc_in: (c, n1, 4) BC(n2) block (what inverse() returns) -> (n/R, 4) contiguous slice."""
+        R, k, c, n2 = self.world, self.k, self.c, self.n2
+        send = x.view(c, R, k, 4).permute(1, 2, 0, 3).contiguous()      # [s][j1 local of s][j2 local]
+        recv = self._exchange(send)                                     # [r][j1 local][j2 local of r]
+        return recv.permute(1, 0, 2, 3).contiguous().view(k * n2, 4)    # [j1 local][j2]: index j1 n2 + j2
+
     def forward(self, x, natural_in=False, natural_out=False):
         """x: (c, n1, 4) int64 tensor, this rank's BC(n2) block (transformed in place as scratch) -> (k, n2, 4), its
         BC(n1) block of the transform.  On one rank the layouts may also be the natural order (x[j] at j in, X[k] at k

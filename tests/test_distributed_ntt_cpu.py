@@ -62,9 +62,17 @@ def _worker(rank, world, port, log_n, l1, ret):
         assert tuple(x.shape[:2]) == d.local_shape_in()
         y = d.forward(x)
         ok_f = np.array_equal(y.numpy().view(np.uint64), d.scatter_out(want)) and tuple(y.shape[:2]) == d.local_shape_out()
+        # natural order across the ranks: one more all-to-all each way
+        per = n // world
+        nat = d.bc_out_to_natural(y.clone())
+        ok_n = np.array_equal(nat.numpy().view(np.uint64), want[rank * per:(rank + 1) * per])
+        ok_n = ok_n and np.array_equal(d.natural_to_bc_out(nat).numpy().view(np.uint64), d.scatter_out(want))
+        x_nat = torch.from_numpy(full[rank * per:(rank + 1) * per].copy().view(np.int64))
+        ok_n = ok_n and np.array_equal(d.natural_to_bc_in(x_nat).numpy().view(np.uint64), d.scatter_in(full))
         back = d.inverse(y)
         ok_i = np.array_equal(back.numpy().view(np.uint64), d.scatter_in(full))
-        ret[rank] = (bool(ok_f), bool(ok_i))
+        ok_i = ok_i and np.array_equal(d.bc_in_to_natural(back).numpy().view(np.uint64), full[rank * per:(rank + 1) * per])
+        ret[rank] = (bool(ok_f and ok_n), bool(ok_i))
     finally:
         dist.destroy_process_group()
 

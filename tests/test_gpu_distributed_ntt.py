@@ -163,8 +163,13 @@ def _worker(rank, world, port, log_n, l1, ret):
         x = torch.from_numpy(d.scatter_in(full).view(np.int64)).cuda()
         y = d.forward(x)
         ok_f = np.array_equal(y.cpu().numpy().view(np.uint64), d.scatter_out(want))
+        per = n // world                                                  # natural order across the ranks: one more all-to-all
+        nat = d.bc_out_to_natural(y.clone())
+        ok_f = ok_f and np.array_equal(nat.cpu().numpy().view(np.uint64), want[rank * per:(rank + 1) * per])
+        ok_f = ok_f and np.array_equal(d.natural_to_bc_out(nat).cpu().numpy().view(np.uint64), d.scatter_out(want))
         back = d.inverse(y)
         ok_i = np.array_equal(back.cpu().numpy().view(np.uint64), d.scatter_in(full))
+        ok_i = ok_i and np.array_equal(d.bc_in_to_natural(back).cpu().numpy().view(np.uint64), full[rank * per:(rank + 1) * per])
         ret[rank] = (bool(ok_f), bool(ok_i))
     finally:
         dist.destroy_process_group()
