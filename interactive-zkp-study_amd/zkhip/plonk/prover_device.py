@@ -259,11 +259,16 @@ class DevicePlonk:
                ("W_zeta_comm", B["q0"], n + 5), ("W_zeta_omega_comm", B["q1"], n + 2)]
         return out + [(k + "_comm", self.coef[k], n) for k in ("q_l", "q_r", "q_o", "q_m", "q_c", "s_sigma1", "s_sigma2", "s_sigma3")]
 
-    def closed_form_mismatches(self, proof, tau, on_host=False):
+    def closed_form_mismatches(self, proof, tau, on_host=False, mul=None):
         """Names of the commitments that differ from p(tau) * G1.  p(tau) comes from the device (scale by the powers of tau,
         running sum: zk_fr_scale_powers_dev + zk_fr_scan_dev) or, on_host, from Horner's rule on Python integers over the
-        downloaded coefficients -- no MSM, no SRS point involved either way."""
+        downloaded coefficients -- no MSM, no SRS point involved either way.  mul(k) -> k * G1 as (x, y) integers | None lets the
+        caller supply the scalar multiplication (tests and tools pass the C oracle's, so that the expected point owes nothing
+        to this library); without it the library's own group operation is used."""
         from ..field import G1, ec_mul
+        if mul is None:
+            mul = lambda k: ec_mul(G1, k)
+        as_ints = lambda pt: None if pt is None else (int(pt[0]), int(pt[1]))
         bad = []
         for name, coef, count in self.committed_polynomials():
             if on_host:
@@ -273,7 +278,7 @@ class DevicePlonk:
             else:
                 val = int(self._evaluate(coef, count, tau))
             have = self.comm[name[:-5]] if name[:-5] in self.comm else getattr(proof, name)   # preprocessing / proof field
-            if have != ec_mul(G1, val):
+            if as_ints(have) != as_ints(mul(val)):
                 bad.append(name)
         return bad
 

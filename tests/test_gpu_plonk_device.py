@@ -119,11 +119,15 @@ def test_device_prover_2pow12_verifies_and_rejects_tampering():
     assert verify(proof, [], pp, Srs)
     # independent of this repo's verifier: tau is known, so every commitment must be p(tau) * G1 -- Horner on Python integers over
     # the downloaded coefficients, and the device's own scale-and-sum evaluation, against one scalar multiplication each
-    assert dev.closed_form_mismatches(proof, tau, on_host=True) == []
-    assert dev.closed_form_mismatches(proof, tau) == []
+    # the expected point is the C ORACLE's scalar multiplication, so nothing of it comes from libzkhip
+    import c_oracle as co
+    oracle_mul = lambda k: co.g1_mul(o.G1, int(k) % o.R)
+    assert dev.closed_form_mismatches(proof, tau, on_host=True, mul=oracle_mul) == []
+    assert dev.closed_form_mismatches(proof, tau, mul=oracle_mul) == []
+    assert dev.closed_form_mismatches(proof, tau) == []               # the library's own group operation agrees
     wrong = copy.copy(proof)
     wrong.t_hi_comm = proof.t_mid_comm
-    assert dev.closed_form_mismatches(wrong, tau) == ["t_hi_comm"]
+    assert dev.closed_form_mismatches(wrong, tau, mul=oracle_mul) == ["t_hi_comm"]
     bad = copy.copy(proof)
     bad.a_eval = proof.a_eval + FR(1)
     assert not verify(bad, [], pp, Srs)
