@@ -11,11 +11,23 @@
 
 namespace zk {
 
-constexpr int FIX_C = 20;
-constexpr int FIX_W = (255 + FIX_C - 1) / FIX_C;                   // 13
-constexpr uint32_t FIX_NB = 1u << (FIX_C - 1);                     // 2^19 buckets
-constexpr uint32_t FIX_G = FIX_NB / SEG_BUCKETS;                   // 2048 cells
-static_assert(FIX_G <= MAX_CELLS, "the one window's cells must fit the scan kernel");
+// The window width is a property of the group: G1 takes 20-bit digits (13 rows, 2^19 buckets).  A G2 addition costs three
+// G1 additions in the accumulate kernel but a G2 bucket costs about the same three in the reduction, whose work grows with the
+// bucket count and not with n: ZK_FIX_C_G2 bits (see profiles/r04_experiments.md) balance the two for the 2^20-point query.
+#ifndef ZK_FIX_C_G2
+#define ZK_FIX_C_G2 20
+#endif
+template <int C_>
+struct FixCfg {
+    static constexpr int C = C_;
+    static constexpr int W = (255 + C - 1) / C;                    // rows of the table / digits per scalar (20: 13, 19: 14, 18: 15)
+    static constexpr uint32_t NB = 1u << (C - 1);                  // buckets of the one window
+    static constexpr uint32_t G = NB / SEG_BUCKETS;                // its cells
+    static_assert(G <= MAX_CELLS, "the one window's cells must fit the scan kernel");
+    static_assert(G == PREP_NT / 2 || G == PREP_NT || G == 2 * PREP_NT, "msm_fixed_partition_kernel holds G / 1024 cells per thread");
+};
+template <class F>
+using FixOf = FixCfg<F::CANON_WORDS == 8 ? 20 : ZK_FIX_C_G2>;
 
 // table[w * stride + i] = 2^(20 w) * P_i as a packed Montgomery affine point (infinity stays the all-zero encoding).
 // The 12 multiples are reached by doubling on in XYZZ coordinates and brought back to affine together: one inversion per point
@@ -30,6 +42,7 @@ __global__ __launch_bounds__(64) void msm_fixed_table_kernel(const uint32_t *__r
     const F x = ld_canonical<F>(points + (size_t)i * 2 * PW), y = ld_canonical<F>(points + (size_t)i * 2 * PW + PW);
     const Affine<F> a = (x.is_zero() && y.is_zero()) ? Affine<F>::inf() : Affine<F>{fe_to_mont(x), fe_to_mont(y)};
     table[i] = pack_affine(Affine<F>{fe_reduce_full(a.x), fe_reduce_full(a.y)});
+    constexpr int FIX_W = FixOf<F>::W, FIX_C = FixOf<F>::C;
     Xyzz<F> rows[FIX_W - 1];
     F before[FIX_W - 1];          // product of the ZZZ of the rows before this one
     Xyzz<F> q = Xyzz<F>::from_affine(a);
@@ -66,10 +79,11 @@ __global__ __launch_bounds__(64) void msm_fixed_table_kernel(const uint32_t *__r
 // makes the top digit uniform over [0, 0.96 * 2^19) like every other row's.  Scalars below 2^240 (their top digit is zero:
 // small / witness-like values keep their few non-zero digits) and non-canonical ones >= 2^254 are left alone.  Not for
 // G2: the twist has a cofactor, and an input outside the order-r subgroup must still give the reference's result.
-template <int DUMMY>
+template <int C>
 __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32_t *__restrict__ scalars, int32_t *__restrict__ digits,
                                                                    uint32_t *__restrict__ cell_total, uint32_t n, uint32_t n_pad, bool spread) {
-    constexpr int C = FIX_C, W = FIX_W;
+    constexpr int W = FixCfg<C>::W;
+    constexpr uint32_t FIX_G = FixCfg<C>::G;
     __shared__ uint32_t hist[FIX_G];
     const uint32_t t = threadIdx.x;
     for (uint32_t k = t; k < FIX_G; k += PREP_NT) hist[k] = 0;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32
         uint32_t s[9];
         ld_words<8>(scalars + (size_t)i * 8, s);
         s[8] = 0;
-        if (spread && (s[7] >> 16) != 0 && (s[7] >> 30) == 0) {
+        if (C == 20 && spread && (s[7] >> 16) != 0 && (s[7] >> 30) == 0) {
             // r as 32-bit words, least significant first
             constexpr uint32_t RW[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
             const uint32_t m = ((i * 0x9E3779B1u) >> 16) % 41u;
@@ -133,10 +147,12 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32
 // the cells' spans and writes the entries out cell by cell; the stored index is the TABLE row  w * stride + first + i
 // (| sign << 31), so the generic accumulate kernel gathers straight from the table.  With 2048 cells a workgroup's share
 // of a cell is only entries / 2048 long: PPT = 8 (8192 entries) gives 16-byte runs and half the cursor atomics of PPT = 4.
-template <int PPT>
+template <int PPT, int C>
 __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int32_t *__restrict__ digits, SortBufs B, uint32_t n_pad, size_t stride,
                                                                      uint32_t first, uint32_t total) {
     constexpr int NE = PREP_NT * PPT;
+    constexpr uint32_t FIX_G = FixCfg<C>::G;
+    constexpr int CPT = FIX_G > PREP_NT ? (int)(FIX_G / PREP_NT) : 1;   // cells per thread (threads past the last cell hold none)
     __shared__ uint32_t hist[FIX_G];   // counts, then exclusive offsets
     __shared__ uint32_t gpos[FIX_G];
     __shared__ uint32_t wave_tot[PREP_NT / 64 + 1];
@@ -145,20 +161,27 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
     __shared__ uint8_t stage_loc[NE];
     const uint32_t t = threadIdx.x;
     const uint32_t v0 = blockIdx.x * NE;
-    // span starts of this thread's two cells: every workgroup scans the 2048 cell totals of the prepare kernel itself (no scan launch
+    const bool owner = t * CPT < FIX_G;
+    // span starts of this thread's cells: every workgroup scans the cell totals of the prepare kernel itself (no scan launch
     // in between; workgroup 0 publishes them for the cell sort, msm_cellsort_kernel zeroes the counters for the next run)
-    uint32_t cb0, cb1;
+    uint32_t cb[CPT];
     {
-        const uint32_t c0 = B.cell_total[2 * t], c1 = B.cell_total[2 * t + 1];
-        const uint32_t p0 = (c0 + 15u) & ~15u, p1 = (c1 + 15u) & ~15u;   // 16-entry aligned spans (the cell sort fetches 16 entries per load)
+        uint32_t cnt[CPT], sum = 0;
+#pragma unroll
+        for (int k = 0; k < CPT; k++) {
+            cnt[k] = owner ? B.cell_total[CPT * t + k] : 0u;
+            cb[k] = sum;
+            sum += (cnt[k] + 15u) & ~15u;   // 16-entry aligned spans (the cell sort fetches 16 entries per load)
+        }
         uint32_t all;
-        cb0 = block_exclusive_scan<PREP_NT>(p0 + p1, wave_tot, &all);
-        cb1 = cb0 + p0;
-        if (blockIdx.x == 0) {
-            B.cell_base[2 * t] = cb0;
-            B.cell_cnt[2 * t] = c0;
-            B.cell_base[2 * t + 1] = cb1;
-            B.cell_cnt[2 * t + 1] = c1;
+        const uint32_t base = block_exclusive_scan<PREP_NT>(sum, wave_tot, &all);
+#pragma unroll
+        for (int k = 0; k < CPT; k++) {
+            cb[k] += base;
+            if (blockIdx.x == 0 && owner) {
+                B.cell_base[CPT * t + k] = cb[k];
+                B.cell_cnt[CPT * t + k] = cnt[k];
+            }
         }
     }
     for (uint32_t k = t; k < FIX_G; k += PREP_NT) hist[k] = 0;
@@ -173,15 +196,23 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
         rk[rep] = dd[rep] != 0 ? atomicAdd(&hist[jj[rep] >> SEG_LOG], 1u) : 0u;
     }
     __syncthreads();
-    // exclusive scan of the 2048 cell counts: two per thread
-    static_assert(FIX_G == 2 * PREP_NT, "two cells per thread");
-    const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
+    // exclusive scan of the cell counts, CPT per thread
+    uint32_t h[CPT], hsum = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+        h[k] = owner ? hist[CPT * t + k] : 0u;
+        hsum += h[k];
+    }
     uint32_t total_here;
-    const uint32_t ex = block_exclusive_scan<PREP_NT>(h0 + h1, wave_tot, &total_here);
-    hist[2 * t] = ex;
-    hist[2 * t + 1] = ex + h0;
-    gpos[2 * t] = h0 ? cb0 + atomicAdd(&B.cell_cursor[2 * t], h0) : 0u;
-    gpos[2 * t + 1] = h1 ? cb1 + atomicAdd(&B.cell_cursor[2 * t + 1], h1) : 0u;
+    uint32_t ex = block_exclusive_scan<PREP_NT>(hsum, wave_tot, &total_here);
+#pragma unroll
+    for (int k = 0; k < CPT; k++) {
+        if (owner) {
+            hist[CPT * t + k] = ex;
+            gpos[CPT * t + k] = h[k] ? cb[k] + atomicAdd(&B.cell_cursor[CPT * t + k], h[k]) : 0u;
+        }
+        ex += h[k];
+    }
     __syncthreads();
 #pragma unroll
     for (int rep = 0; rep < PPT; rep++) {

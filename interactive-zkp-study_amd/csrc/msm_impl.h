@@ -1088,8 +1088,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
             fix_table.release();
             return ZK_OK;
         }
+        constexpr int FIX_W = FixOf<F>::W;
         if (pick_window_bits(cap_n) != 16) throw std::runtime_error("zk_msm_plan_bind_points: the plan must be created for more than 2^17 points");
-        if ((uint64_t)FIX_W * n >= ((uint64_t)1 << 31)) throw std::runtime_error("zk_msm_plan_bind_points: too many bases (13 n must stay below 2^31)");
+        if ((uint64_t)FIX_W * n >= ((uint64_t)1 << 31)) throw std::runtime_error("zk_msm_plan_bind_points: too many bases (rows * n must stay below 2^31)");
         for (int i = 0; i < nlanes; i++)
             if (lanes[i].busy) throw std::runtime_error("zk_msm_plan_bind_points: submissions outstanding");
         fix_n = 0;
@@ -1109,6 +1110,9 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         throw std::runtime_error("zk_msm: too many submissions in flight (zk_msm_plan_max_in_flight); collect one first");
     }
     int submit_lane_fixed(const void *d_scalars, size_t first, size_t n, hipStream_t st) {
+        using Cfg = FixOf<F>;
+        constexpr int FIX_C = Cfg::C, FIX_W = Cfg::W;
+        constexpr uint32_t FIX_NB = Cfg::NB, FIX_G = Cfg::G;
         const int ticket = pick_lane();
         Lane &L = lanes[ticket];
         prepare_lane(L);
@@ -1125,7 +1129,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         ZK_HIP(hipEventRecord(L.ev_in, st));
         ZK_HIP(hipStreamWaitEvent(ls, L.ev_in, 0));
         mark(L, 0);
-        hipLaunchKernelGGL((msm_fixed_prepare_kernel<0>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, ls, static_cast<const uint32_t *>(d_scalars),
+        hipLaunchKernelGGL((msm_fixed_prepare_kernel<FIX_C>), dim3(n_pad / (PREP_NT * PREP_PPT)), dim3(PREP_NT), 0, ls, static_cast<const uint32_t *>(d_scalars),
                            L.digits32.template as<int32_t>(), L.cells.template as<uint32_t>(), (uint32_t)n, n_pad, F::CANON_WORDS == 8);
         ZK_HIP(hipEventRecord(L.ev_consumed, ls));
         ZK_HIP(hipStreamWaitEvent(st, L.ev_consumed, 0));
@@ -1135,7 +1139,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const PackedAffine<F> *table = fix_table.template as<PackedAffine<F>>();
         constexpr int FIX_PPT = 8;
         const uint32_t fix_total = (uint32_t)FIX_W * n_pad;
-        hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
+        hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT, FIX_C>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
                            L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total);
         hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(FIX_G, 1), dim3(CS_NT), 0, ls, B, FIX_NB);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, ls, B);
@@ -1151,7 +1155,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(L, 6);
         hipLaunchKernelGGL((msm_boundary_kernel<0>), dim3(1024), dim3(64), 0, L.stream, err_dev(L));
         mark(L, 3);
-        const uint32_t levels = FIX_C - 1, BL = 9;
+        const uint32_t levels = FIX_C - 1, BL = FIX_C - 11;   // 1024 one-wavefront workgroups: one per SIMD
         hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3(FIX_NB >> BL), dim3(64), 0, ls, L.arena.template as<Xyzz<F>>(), BL);
         for (uint32_t step = 0; step < levels - BL; step++) {
             const uint32_t ntasks = (step + 1 + BL) << (levels - BL - 1 - step);
