@@ -758,7 +758,9 @@ __global__ __launch_bounds__(64, 2) void msm_reduce_wave_kernel(Xyzz<F> *x, uint
 
 // One workgroup per window: the upper levels of the pair tree over the block totals (and their odd
 // trees), plus, for every level below BL, the plain sum over the blocks of that level's per-block
-// odd partial.  Then out[w][l] = O_l (l < levels), out[w][levels] = T.
+// odd partial.  Then out[w][l] = O_l (l < levels), out[w][levels] = T.  A "window" may also be an aligned GROUP of blocks of a
+// larger window (out == nullptr: the results stay in place at win[2^l] and win[0]), and its "blocks" may be such groups already
+// reduced (BL = log2 of the group size): the bound-bases mode reduces its 2^19-bucket window in two such launches.
 template <class F>
 __global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz<F> *__restrict__ out, uint32_t nb, uint32_t BL,
                                                                 uint32_t levels) {
@@ -790,44 +792,7 @@ __global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz
         }
         __syncthreads();
     }
-    if (t <= levels) out[(size_t)blockIdx.x * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
-}
-
-// The same upper-tree step as one launch per step, spread over many workgroups (grid.x covers the tasks, grid.y the
-// windows): for windows with many blocks (the 2^19-bucket window of the bound-bases mode has 1024) a single workgroup
-// per window would run tens of dependent addition rounds.  The last step's launch also writes out[].
-template <class F>
-__global__ __launch_bounds__(256) void msm_reduce_window_step_kernel(Xyzz<F> *x, Xyzz<F> *__restrict__ out, uint32_t nb, uint32_t BL, uint32_t levels,
-                                                                     uint32_t s, uint32_t write_out) {
-    Xyzz<F> *win = x + (size_t)blockIdx.y * nb;
-    const uint32_t UL = levels - BL;
-    if (!write_out) {
-        const uint32_t sh = UL - 1 - s, per = 1u << sh;
-        const uint32_t ntasks = (s + 1 + BL) * per;
-        const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-        if (q >= ntasks) return;
-        const uint32_t grp = q >> sh, i = q & (per - 1u);
-        uint32_t dst, src;
-        if (grp == s) {
-            dst = (i << (s + 1)) << BL;
-            src = dst + ((1u << s) << BL);
-        } else if (grp < s) {
-            const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
-            dst = ((2 * j + 1) << l) << BL;
-            src = ((2 * (j + (1u << k)) + 1) << l) << BL;
-        } else {
-            const uint32_t l = grp - s - 1;
-            dst = ((i << (s + 1)) << BL) + (1u << l);
-            src = dst + ((1u << s) << BL);
-        }
-        Xyzz<F> a = win[dst];
-        const Xyzz<F> b = win[src];
-        xyzz_add(a, b);
-        win[dst] = a;
-    } else {
-        const uint32_t t = threadIdx.x;
-        if (blockIdx.x == 0 && t <= levels) out[(size_t)blockIdx.y * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
-    }
+    if (out != nullptr && t <= levels) out[(size_t)blockIdx.x * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -1157,13 +1122,15 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(L, 3);
         const uint32_t levels = FIX_C - 1, BL = FIX_C - 11;   // 1024 one-wavefront workgroups: one per SIMD
         hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3(FIX_NB >> BL), dim3(64), 0, ls, L.arena.template as<Xyzz<F>>(), BL);
-        for (uint32_t step = 0; step < levels - BL; step++) {
-            const uint32_t ntasks = (step + 1 + BL) << (levels - BL - 1 - step);
-            hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3((ntasks + 255) / 256, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(),
-                               out_dev(L), FIX_NB, BL, levels, step, 0u);
-        }
-        hipLaunchKernelGGL((msm_reduce_window_step_kernel<F>), dim3(1, 1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(), out_dev(L),
-                           FIX_NB, BL, levels, 0u, 1u);
+        // The ten levels above the blocks in TWO launches of the window kernel: 32 groups of 32 blocks each reduce as if they were
+        // windows of their own (five steps, at most 160 tasks: one addition round per step in a 256-thread workgroup, one wavefront
+        // per SIMD), then one workgroup takes the 32 group results as "blocks" of 2^(BL+5) buckets (five steps, at most 240 tasks)
+        // and writes the level sums out.  (Eleven single-step launches before, the same ten dependent rounds plus their launch gaps: reduce span of a 2^20-point
+        // bound MSM 0.274 -> 0.254 ms in G1, 0.867 -> 0.798 ms in G2; profiles/r04_experiments.md.)
+        constexpr uint32_t GL = 5;
+        hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(FIX_NB >> (BL + GL)), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(),
+                           static_cast<Xyzz<F> *>(nullptr), 1u << (BL + GL), BL, BL + GL);
+        hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(), out_dev(L), FIX_NB, BL + GL, levels);
         mark(L, 4);
         ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, OUT_HDR + (size_t)(levels + 1) * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, ls));
         ZK_HIP(hipEventRecord(L.done, ls));
