@@ -32,7 +32,7 @@ def mulmod_limbs(vals):
     return _lib.ints_to_limbs(vals)
 
 
-def run(log_n, reps, profile=False):
+def run(log_n, reps, profile=False, pause_after_proofs=0.0):
     import torch
     from zkhip import _lib
     from zkhip.field import CURVE_ORDER as R, G1, G2, fixed_base_mul, get_root_of_unity
@@ -102,6 +102,8 @@ def run(log_n, reps, profile=False):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
 
+    if pause_after_proofs:                          # a kernel trace can then be cut at this pause (tools/trace_window.py --before-gap-ms)
+        time.sleep(pause_after_proofs)
     if profile:                                     # where the HOST time of one prove() goes (cumulative, top entries)
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -132,5 +134,6 @@ if __name__ == "__main__":
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true", help="cProfile one more prove() and print the host-side hot spots to stderr")
+    ap.add_argument("--pause-after-proofs", type=float, default=0.0, help="seconds of GPU idleness between the timed proofs and the checks (marks the end of the last proof in a kernel trace)")
     args = ap.parse_args()
-    print(json.dumps(run(args.log_n, args.reps, args.profile)), flush=True)
+    print(json.dumps(run(args.log_n, args.reps, args.profile, args.pause_after_proofs)), flush=True)

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("dir")
     ap.add_argument("--window-ms", type=float, default=11.0)
     ap.add_argument("--anchor", default="", help="end the window at the last kernel whose name contains this")
+    ap.add_argument("--before-gap-ms", type=float, default=0.0, help="end the window where the last GPU pause longer than this begins")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
     f = sorted(glob.glob(os.path.join(a.dir, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
@@ -25,6 +26,12 @@ def main():
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Queue_Id"]) for r in csv.DictReader(open(f)))
     anchored = [e for e in ev if a.anchor in e[2]] if a.anchor else ev
     tend = anchored[-1][1]
+    if a.before_gap_ms:   # end at the last kernel before the LAST pause of the GPU longer than this (a tool's host-side checks after its timed proofs)
+        last = ev[0][1]
+        for s, e, n, q in ev:
+            if s - last > a.before_gap_ms * 1e6:
+                tend = last
+            last = max(last, e)
     t0 = tend - int(a.window_ms * 1e6)
     win = [e for e in ev if t0 <= e[0] and e[1] <= tend + 1000]
     base = win[0][0]
