@@ -622,6 +622,15 @@ template <class Tag> ZK_HD Fe<Tag> fe_inv(const Fe<Tag> &a) {
     return fe_pow(a, e);
 }
 
+// c ? a : b limb by limb (v_cndmask): the ?: operator on two element lvalues selects between their ADDRESSES, which parks both in scratch memory
+template <class Tag> ZK_HD Fe<Tag> fe_select(bool c, const Fe<Tag> &a, const Fe<Tag> &b) {
+    Fe<Tag> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    ZK_DBG(r.vb = c ? a.vb : b.vb; r.lmax = c ? a.lmax : b.lmax;)
+    return r;
+}
+
 typedef Fe<FpTag> Fp;
 typedef Fe<FrTag> Fr;
 
@@ -653,6 +662,7 @@ struct Fp2 {
     ZK_HD bool equals(const Fp2 &b) const { return c0.equals(b.c0) && c1.equals(b.c1); }
 };
 
+ZK_HD Fp2 fe_select(bool c, const Fp2 &a, const Fp2 &b) { return Fp2{fe_select(c, a.c0, b.c0), fe_select(c, a.c1, b.c1)}; }
 ZK_HD Fp2 fe_add(const Fp2 &a, const Fp2 &b) {
     Fp2 r{fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)};
     fe_wreduce<4>(r.c0);

@@ -12,8 +12,9 @@
 //   accumulate   one thread per bucket, one wavefront per workgroup, lists of equal length side by side; XYZZ mixed
 //                additions (8M+2S).  Lists longer than heavy_th are summed by the first workgroups of the same grid (wavefront
 //                tasks of 64 segments, __shfl trees, per-bucket last-arriver combine), beside the ordinary lists.
-//   reduce       sum_j (j+1)*B_j per window without any serial running sum, in place: pair levels plus plain-sum trees
-//                over the odd entries of every level (sum_j j*B_j = sum_l 2^l * O_l).
+//   reduce       sum_j (j+1)*B_j per window without any serial running sum, in place (msm_reduce.h): the index bits are folded
+//                from the top down, every fold leaving behind the plain sum of one bit's buckets; the lower levels one lane per
+//                addition, the upper ones on teams of two and four lanes (DPP exchange) that shorten the dependent chain.
 //   fold (host)  the W*c window/level sums are read back and combined by one 254-doubling Horner pass on the host
 //                (a single GPU thread would be latency-bound); it hides behind the next MSM's kernels.
 //
@@ -24,6 +25,7 @@
 #include "curve.h"
 #include "host_field.h"
 #include "msm.h"
+#include "msm_reduce.h"
 
 namespace zk {
 
@@ -692,109 +694,6 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumul
 }
 // [accumulate-kernel-end]
 
-// A grid of workgroups that do nothing, launched between the accumulate kernel and the bucket reduction (profiles/r04_experiments.md,
-// section 3): with the reduction's first kernel directly behind the accumulate kernel that kernel takes 25 % longer (G1 0.28 instead of
-// 0.22 ms, G2 0.87 instead of 0.70 ms for 2^20 points, in every A/B pair) -- its 1024 one-wavefront workgroups are then not spread one
-// per SIMD.  A pass of 1024 empty workgroups in between restores the spread (a one-workgroup no-op does not, an LDS reservation
-// does not); launching the reduction as 256 workgroups of four wavefronts avoids the penalty too, 3 % behind this form.  Until
-// round 4 the (normally empty) heavy-bucket kernel sat here and did this by accident.
-template <int DUMMY> __global__ void msm_boundary_kernel(const uint32_t *p) {
-    if (p == nullptr && threadIdx.x == 999) __builtin_trap();   // never taken (p is the lane's error counter): keeps the body from being empty
-}
-
-// ------------------------------------------------------------------------------ reduce
-// Per window: R_w = sum_j (j+1) * B_j = T + sum_l 2^l * O_l, where T is the plain sum of the
-// window's buckets and O_l the plain sum of the ODD entries of level l of the pairwise-sum tree
-// (L_0 = B, L_{l+1}[j] = L_l[2j] + L_l[2j+1]); no serial running sum anywhere.  Everything runs IN
-// PLACE in the bucket array x[]:
-//   pair step s:       x[i * 2^(s+1)] += x[i * 2^(s+1) + 2^s]       (level s+1 lives at stride 2^(s+1))
-//   the odd entries of level l sit at x[2^l * (2j+1)] and are never written again by pair steps, so
-//   their plain sum is a second in-place tree over j:  x[2^l (2j+1)] += x[2^l (2(j + 2^k) + 1)],
-//   which for level l starts one step after pair step l.  At step s the pair tree and the odd trees
-//   of all lower levels together need (s+1) * (half >> s) <= half additions: one EC addition per
-//   thread per step, depth = number of levels.
-// Afterwards O_l = x[2^l] and T = x[0] (per block for the block kernel, per window at the end).
-// Block phase: ONE wavefront per block of 2^BL buckets (BL >= 6).  Lane t first runs steps 0 .. m-1 (m = BL - 6) of the
-// algorithm on its own 2^m consecutive buckets, serially and with no synchronisation -- every lane busy, 2 * 2^m - 2 - m additions --
-// then the 64 lanes run steps m .. BL-1 over the block together: 11 + 8 addition steps for a 512-bucket block, one wavefront per
-// SIMD.  (A 256-thread workgroup per block with one task per thread and step keeps (s+1) * 2^(BL-1-s) threads busy at step s -- 44 %
-// over the nine steps -- at four wavefronts per SIMD: the whole reduce stage of a 2^20-point MSM went 0.256 -> 0.225 ms (G1) and
-// 0.83 -> 0.69 ms (G2); blocks of 256 or 1024 buckets are slower: profiles/r02_experiments.md.)
-template <class F>
-__device__ __forceinline__ void reduce_task(Xyzz<F> *base, uint32_t s, uint32_t sh, uint32_t q) {
-    const uint32_t grp = q >> sh, i = q & ((1u << sh) - 1u);
-    uint32_t dst, src;
-    if (grp == s) {  // pair tree, level s -> s+1
-        dst = i << (s + 1);
-        src = dst + (1u << s);
-    } else {  // odd tree of level grp, its step k
-        const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
-        dst = (2 * j + 1) << l;
-        src = (2 * (j + (1u << k)) + 1) << l;
-    }
-    Xyzz<F> a = base[dst];
-    const Xyzz<F> b = base[src];
-    xyzz_add(a, b);
-    base[dst] = a;
-}
-template <class F>
-__global__ __launch_bounds__(64, 2) void msm_reduce_wave_kernel(Xyzz<F> *x, uint32_t BL) {
-    Xyzz<F> *blk = x + ((size_t)blockIdx.x << BL);
-    const uint32_t lane = threadIdx.x, m = BL - 6;
-    Xyzz<F> *mine = blk + ((size_t)lane << m);
-    for (uint32_t s = 0; s < m; s++) {
-        const uint32_t sh = m - 1 - s, ntasks = (s + 1) << sh;
-#pragma unroll 1
-        for (uint32_t q = 0; q < ntasks; q++) reduce_task(mine, s, sh, q);
-    }
-    __syncthreads();
-    for (uint32_t s = m; s < BL; s++) {
-        const uint32_t sh = BL - 1 - s, ntasks = (s + 1) << sh;
-#pragma unroll 1
-        for (uint32_t q = lane; q < ntasks; q += 64) reduce_task(blk, s, sh, q);
-        __syncthreads();
-    }
-}
-
-// One workgroup per window: the upper levels of the pair tree over the block totals (and their odd
-// trees), plus, for every level below BL, the plain sum over the blocks of that level's per-block
-// odd partial.  Then out[w][l] = O_l (l < levels), out[w][levels] = T.  A "window" may also be an aligned GROUP of blocks of a
-// larger window (out == nullptr: the results stay in place at win[2^l] and win[0]), and its "blocks" may be such groups already
-// reduced (BL = log2 of the group size): the bound-bases mode reduces its 2^19-bucket window in two such launches.
-template <class F>
-__global__ __launch_bounds__(512) void msm_reduce_window_kernel(Xyzz<F> *x, Xyzz<F> *__restrict__ out, uint32_t nb, uint32_t BL,
-                                                                uint32_t levels) {
-    Xyzz<F> *win = x + (size_t)blockIdx.x * nb;
-    const uint32_t t = threadIdx.x;
-    const uint32_t UL = levels - BL;  // log2(blocks per window)
-    for (uint32_t s = 0; s < UL; s++) {
-        const uint32_t sh = UL - 1 - s, per = 1u << sh;
-        const uint32_t ntasks = (s + 1 + BL) * per;
-        for (uint32_t q = t; q < ntasks; q += blockDim.x) {
-            const uint32_t grp = q >> sh, i = q & (per - 1u);
-            uint32_t dst, src;
-            if (grp == s) {  // upper pair tree
-                dst = (i << (s + 1)) << BL;
-                src = dst + ((1u << s) << BL);
-            } else if (grp < s) {  // odd tree of upper level BL + grp
-                const uint32_t l = grp, k = s - l - 1, j = i << (k + 1);
-                dst = ((2 * j + 1) << l) << BL;
-                src = ((2 * (j + (1u << k)) + 1) << l) << BL;
-            } else {  // plain sum over blocks of the per-block odd partial of level l < BL
-                const uint32_t l = grp - s - 1;
-                dst = ((i << (s + 1)) << BL) + (1u << l);
-                src = dst + ((1u << s) << BL);
-            }
-            Xyzz<F> a = win[dst];
-            const Xyzz<F> b = win[src];
-            xyzz_add(a, b);
-            win[dst] = a;
-        }
-        __syncthreads();
-    }
-    if (out != nullptr && t <= levels) out[(size_t)blockIdx.x * (levels + 1) + t] = (t < levels) ? win[1u << t] : win[0];
-}
-
 // ------------------------------------------------------------------------------ host side
 static int pick_window_bits(size_t n) {
     // Measured on MI355X (blocking and pipelined, n = 2^2 .. 2^19): below ~2^9 points everything is launch latency and the
@@ -1023,7 +922,6 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                            L.perm.template as<uint32_t>(), L.arena.template as<Xyzz<F>>(), nbuckets, B.heavy_th, B,
                            L.heavy_partial.template as<Xyzz<F>>(), heavy_blocks);
         mark(L, 6);
-        hipLaunchKernelGGL((msm_boundary_kernel<0>), dim3(1024), dim3(64), 0, L.stream, err_dev(L));
     }
 
     // Enqueues the whole GPU pipeline plus the 36 KiB read-back; returns a ticket.  The work runs on the lane's own
@@ -1118,19 +1016,16 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
                            L.counts.template as<uint32_t>(), L.bucket_off.template as<uint32_t>(), L.perm.template as<uint32_t>(),
                            L.arena.template as<Xyzz<F>>(), FIX_NB, B.heavy_th, B, L.heavy_partial.template as<Xyzz<F>>(), heavy_blocks);
         mark(L, 6);
-        hipLaunchKernelGGL((msm_boundary_kernel<0>), dim3(1024), dim3(64), 0, L.stream, err_dev(L));
         mark(L, 3);
-        const uint32_t levels = FIX_C - 1, BL = FIX_C - 11;   // 1024 one-wavefront workgroups: one per SIMD
-        hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3(FIX_NB >> BL), dim3(64), 0, ls, L.arena.template as<Xyzz<F>>(), BL);
-        // The ten levels above the blocks in TWO launches of the window kernel: 32 groups of 32 blocks each reduce as if they were
-        // windows of their own (five steps, at most 160 tasks: one addition round per step in a 256-thread workgroup, one wavefront
-        // per SIMD), then one workgroup takes the 32 group results as "blocks" of 2^(BL+5) buckets (five steps, at most 240 tasks)
-        // and writes the level sums out.  (Eleven single-step launches before, the same ten dependent rounds plus their launch gaps: reduce span of a 2^20-point
-        // bound MSM 0.274 -> 0.254 ms in G1, 0.867 -> 0.798 ms in G2; profiles/r04_experiments.md.)
-        constexpr uint32_t GL = 5;
-        hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(FIX_NB >> (BL + GL)), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(),
+        // The block kernel takes the lowest RED_BL index bits (256 workgroups); the eight levels above them run in TWO launches of the
+        // window kernel: 16 groups of 16 blocks reduce as if they were windows of their own (four steps, at most 96 team additions
+        // each), then one workgroup takes the 16 group results as "blocks" of 2^(RED_BL+4) buckets and writes the level sums out.
+        constexpr uint32_t levels = FIX_C - 1, BL = RED_BL, GL = (levels - BL) / 2;
+        constexpr int WNT = RED_WINDOW_NT;
+        hipLaunchKernelGGL((msm_reduce_block_kernel<F, RED_BLOCK_NT>), dim3(FIX_NB >> BL), dim3(RED_BLOCK_NT), 0, ls, L.arena.template as<Xyzz<F>>(), BL, static_cast<uint64_t *>(nullptr));
+        hipLaunchKernelGGL((msm_reduce_window_kernel<F, WNT>), dim3(FIX_NB >> (BL + GL)), dim3(WNT), 0, ls, L.arena.template as<Xyzz<F>>(),
                            static_cast<Xyzz<F> *>(nullptr), 1u << (BL + GL), BL, BL + GL);
-        hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(1), dim3(256), 0, ls, L.arena.template as<Xyzz<F>>(), out_dev(L), FIX_NB, BL + GL, levels);
+        hipLaunchKernelGGL((msm_reduce_window_kernel<F, WNT>), dim3(1), dim3(WNT), 0, ls, L.arena.template as<Xyzz<F>>(), out_dev(L), FIX_NB, BL + GL, levels);
         mark(L, 4);
         ZK_HIP(hipMemcpyAsync(L.h_out.p, L.out.p, OUT_HDR + (size_t)(levels + 1) * sizeof(Xyzz<F>), hipMemcpyDeviceToHost, ls));
         ZK_HIP(hipEventRecord(L.done, ls));
@@ -1213,9 +1108,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         mark(L, 3);
         {
             Xyzz<F> *ar = L.arena.template as<Xyzz<F>>();
-            const uint32_t BL = std::min<uint32_t>(9, levels);
-            hipLaunchKernelGGL((msm_reduce_wave_kernel<F>), dim3((W * nb) >> BL), dim3(64), 0, L.stream, ar, BL);
-            hipLaunchKernelGGL((msm_reduce_window_kernel<F>), dim3(W), dim3(512), 0, L.stream, ar, out_dev(L), nb, BL, levels);
+            const uint32_t BL = std::min<uint32_t>(RED_BL, levels);
+            constexpr int WNT = RED_WINDOW_NT;
+            hipLaunchKernelGGL((msm_reduce_block_kernel<F, RED_BLOCK_NT>), dim3((W * nb) >> BL), dim3(RED_BLOCK_NT), 0, L.stream, ar, BL, static_cast<uint64_t *>(nullptr));
+            hipLaunchKernelGGL((msm_reduce_window_kernel<F, WNT>), dim3(W), dim3(WNT), 0, L.stream, ar, out_dev(L), nb, BL, levels);
         }
         mark(L, 4);
         const size_t out_bytes = OUT_HDR + (size_t)W * (levels + 1) * sizeof(Xyzz<F>);

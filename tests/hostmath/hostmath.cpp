@@ -3,6 +3,8 @@
 // Montgomery conversions, XYZZ formulas, exceptional cases) against the oracle without a GPU, and
 // the host epilogue types of host_field.h (device <-> host conversions).  Not part of the product.
 #include <string.h>
+#include <pthread.h>
+#include <thread>
 #include "curve.h"
 #include "host_field.h"
 using namespace zk;
@@ -59,6 +61,42 @@ static void g2_store(uint64_t *o, const G2Xyzz &p) {
 }
 static void k32(const uint64_t *k, uint32_t out[8]) { words_of(k, out); }
 
+// The bucket reduction's team additions (curve.h team4_add / team2_add) with the lanes of one aligned group of four as host
+// threads: every fetch publishes the lane's value, meets the other lanes at a barrier and reads the lane the pattern names --
+// what v_mov_b32_dpp quad_perm does for the lanes of a wavefront, which run in lockstep.
+struct HostQuadShared {
+    pthread_barrier_t bar;
+    alignas(16) unsigned char slot[4][sizeof(Fp2)];
+};
+struct HostQuad {
+    HostQuadShared *sh;
+    int lane;
+    template <int P0, int P1, int P2, int P3, class V> V get(const V &x) const {
+        static_assert(sizeof(V) <= sizeof(Fp2), "slot too small");
+        const int perm[4] = {P0, P1, P2, P3};
+        memcpy(sh->slot[lane], &x, sizeof(V));
+        pthread_barrier_wait(&sh->bar);
+        V r;
+        memcpy(&r, sh->slot[perm[lane]], sizeof(V));
+        pthread_barrier_wait(&sh->bar);
+        return r;
+    }
+};
+// lanes: 4 (one team of four on acc[0] += q[0]) or 2 (two teams of two side by side: acc[0] += q[0] and acc[1] += q[1])
+template <class F> static void team_add_threads(int lanes, Xyzz<F> *acc, const Xyzz<F> *q) {
+    HostQuadShared sh;
+    pthread_barrier_init(&sh.bar, nullptr, 4);
+    std::thread th[4];
+    for (int lane = 0; lane < 4; lane++)
+        th[lane] = std::thread([&, lane] {
+            HostQuad ex{&sh, lane};
+            if (lanes == 4) team4_add((uint32_t)lane, &acc[0], &q[0], ex);
+            else team2_add((uint32_t)(lane & 1), &acc[lane >> 1], &q[lane >> 1], ex);
+        });
+    for (auto &t : th) t.join();
+    pthread_barrier_destroy(&sh.bar);
+}
+
 // fe_add_r2 / fe_sub_r2 against the two-chain forms they replace, on RAW normalised 9-limb operands (values < 2m): both results
 // as raw limbs, so the test can demand the very same representative.  which: 0 = F_p, 1 = F_r; op: 0 = add, 1 = sub.
 template <class T> static void r2_pair(int op, const uint32_t *a9, const uint32_t *b9, uint32_t *fast9, uint32_t *ref9) {
@@ -109,7 +147,10 @@ void hm_g2_mul(const uint64_t *p, const uint64_t *k, uint64_t *o) {
     uint32_t kk[8]; k32(k, kk);
     g2_store(o, xyzz_scalar_mul(g2_load(p), kk));
 }
-// mode 0: mixed add (xyzz(p) + affine q); 1: full add after scaling both by scalar muls (k1*p + k2*q)
+// mode 0: mixed add (xyzz(p) + affine q); 1: full add after scaling both by scalar muls (k1*p + k2*q);
+// 2: the same full add by the four-lane team addition of the bucket reduction (curve.h team4_add), lanes as host threads;
+// 3: mode 2 on accumulators that come out of the mixed addition (the lazy bounds the reduction's first level really sees);
+// 4, 5: modes 2, 3 by two teams of two lanes side by side (team2_add; the second team adds q + acc)
 void hm_g1_add(int mode, const uint64_t *p, const uint64_t *q, const uint64_t *k1, const uint64_t *k2, uint64_t *o) {
     if (mode == 0) {
         G1Xyzz a = G1Xyzz::from_affine(g1_load(p));
@@ -118,7 +159,25 @@ void hm_g1_add(int mode, const uint64_t *p, const uint64_t *q, const uint64_t *k
     } else {
         uint32_t a8[8], b8[8]; k32(k1, a8); k32(k2, b8);
         G1Xyzz a = xyzz_scalar_mul(g1_load(p), a8), b = xyzz_scalar_mul(g1_load(q), b8);
-        xyzz_add(a, b);
+        if (mode == 3 || mode == 5) {   // (k1*p + q) and (k2*q + p), each ending in a mixed addition
+            xyzz_add_affine(a, g1_load(q));
+            xyzz_add_affine(b, g1_load(p));
+        }
+        if (mode >= 4) {
+            G1Xyzz acc2[2] = {a, b}, q2[2] = {b, a};
+            team_add_threads(2, acc2, q2);
+            a = acc2[0];
+            G1Affine x = xyzz_to_affine(a), y = xyzz_to_affine(acc2[1]);     // b + a must be the same point
+            const bool same = x.is_inf() ? y.is_inf() : (!y.is_inf() && x.x.equals(y.x) && x.y.equals(y.y));
+            if (!same) {   // no valid encoding: the caller's comparison fails
+                memset(o, 0xff, 8 * sizeof(uint64_t));
+                return;
+            }
+        } else if (mode >= 2) {
+            team_add_threads(4, &a, &b);
+        } else {
+            xyzz_add(a, b);
+        }
         g1_store(o, a);
     }
 }
@@ -130,7 +189,25 @@ void hm_g2_add(int mode, const uint64_t *p, const uint64_t *q, const uint64_t *k
     } else {
         uint32_t a8[8], b8[8]; k32(k1, a8); k32(k2, b8);
         G2Xyzz a = xyzz_scalar_mul(g2_load(p), a8), b = xyzz_scalar_mul(g2_load(q), b8);
-        xyzz_add(a, b);
+        if (mode == 3 || mode == 5) {   // (k1*p + q) and (k2*q + p), each ending in a mixed addition
+            xyzz_add_affine(a, g2_load(q));
+            xyzz_add_affine(b, g2_load(p));
+        }
+        if (mode >= 4) {
+            G2Xyzz acc2[2] = {a, b}, q2[2] = {b, a};
+            team_add_threads(2, acc2, q2);
+            a = acc2[0];
+            G2Affine x = xyzz_to_affine(a), y = xyzz_to_affine(acc2[1]);     // b + a must be the same point
+            const bool same = x.is_inf() ? y.is_inf() : (!y.is_inf() && x.x.equals(y.x) && x.y.equals(y.y));
+            if (!same) {   // no valid encoding: the caller's comparison fails
+                memset(o, 0xff, 16 * sizeof(uint64_t));
+                return;
+            }
+        } else if (mode >= 2) {
+            team_add_threads(4, &a, &b);
+        } else {
+            xyzz_add(a, b);
+        }
         g2_store(o, a);
     }
 }

@@ -94,6 +94,28 @@ def test_add_exceptional_cases(hm):
         assert g2add(hm, 1, A2, A2, k1, k2) == o.g2_multiply(A2, (k1 + k2) % o.R)
 
 
+def test_team_add(hm):
+    """curve.h team4_add / team2_add (the bucket reduction's additions by four or two lanes), the lanes run as host threads that
+    meet at a barrier in every exchange: the general case, acc == q (doubling in role 0), acc == -q, either or both operands infinity --
+    on operands out of scalar multiplications (modes 2, 4) and out of the mixed addition, whose lazier coordinates are what the first
+    reduction level is given (modes 3, 5); the _dbg build checks every product's contract."""
+    rnd = random.Random(11)
+    A, B = o.g1_multiply(o.G1, 123), o.g1_multiply(o.G1, 456)
+    A2, B2 = o.g2_multiply(o.G2, 123), o.g2_multiply(o.G2, 456)
+    pairs = [(5, 7), (5, 5), (5, o.R - 5), (0, 5), (5, 0), (0, 0), (1, 1), (1, o.R - 1)] + [(rnd.randrange(o.R), rnd.randrange(o.R)) for _ in range(4)]
+    for k1, k2 in pairs:
+        for m in (2, 4):
+            assert g1add(hm, m, A, A, k1, k2) == o.g1_multiply(A, (k1 + k2) % o.R)
+            assert g1add(hm, m, A, B, k1, k2) == o.g1_add(o.g1_multiply(A, k1), o.g1_multiply(B, k2))
+            assert g2add(hm, m, A2, A2, k1, k2) == o.g2_multiply(A2, (k1 + k2) % o.R)
+            assert g2add(hm, m, A2, B2, k1, k2) == o.g2_add(o.g2_multiply(A2, k1), o.g2_multiply(B2, k2))
+            # lazy operands: (k1 A + B) + (k2 B + A), and with B = A: (k1 + 1) A + (k2 + 1) A -- equal / opposite operands again
+            assert g1add(hm, m + 1, A, B, k1, k2) == o.g1_add(o.g1_multiply(A, (k1 + 1) % o.R), o.g1_multiply(B, (k2 + 1) % o.R))
+            assert g1add(hm, m + 1, A, A, k1, k2) == o.g1_multiply(A, (k1 + k2 + 2) % o.R)
+            assert g2add(hm, m + 1, A2, B2, k1, k2) == o.g2_add(o.g2_multiply(A2, (k1 + 1) % o.R), o.g2_multiply(B2, (k2 + 1) % o.R))
+            assert g2add(hm, m + 1, A2, A2, k1, k2) == o.g2_multiply(A2, (k1 + k2 + 2) % o.R)
+
+
 def test_small_mul(hm):
     A = o.g1_multiply(o.G1, 99)
     for k in (0, 1, 2, 255, 32768, 65535):
