@@ -712,8 +712,21 @@ def main():
         ready = torch.tensor([1.0 if dg is not None else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(ready, op=dist.ReduceOp.MIN)
         if float(ready.item()) == 1.0:
-            try:   # the same code runs on every rank: a failure in here is symmetric, and must not take the headline line with it
+            # One proof first, then every rank says whether its own went through BEFORE anyone starts the timed ones: a failure that
+            # is local to a rank and shows after its collectives (a device error surfaced at collect_partial, say) is then an error
+            # entry on every rank instead of a rank missing from the next all-to-all.  (A rank that dies INSIDE a collective leaves
+            # the others to the process group's timeout; nothing short of a second process group can turn that into an entry.)
+            proof, first_ok = None, 1.0
+            try:
                 proof = dg.prove(d_wit, 4106, 4565)
+            except Exception as exc:  # noqa: BLE001
+                first_ok = 0.0
+                sys.stderr.write("dist_groth16 proof failed on rank %d: %r\n" % (rank, exc))
+            agreed = torch.tensor([first_ok], dtype=torch.float64, device=cdev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            try:
+                if float(agreed.item()) != 1.0:
+                    raise RuntimeError("a rank's first distributed proof failed (see stderr)")
                 fence()
                 tms = []
                 for _ in range(4):
@@ -845,6 +858,13 @@ def main():
 
     # ---- secondary: Groth16 prove() wall-clock on a synthetic 2^20-constraint R1CS (BASELINE.json configs[3])
     if args.groth16_log_m and world == 1:
+        if os.environ.get("ZK_BENCH_EXPERIMENT") == "close_plan":   # experiment (profiles/r05_experiments.md): nothing of the headline left alive
+            plan.close()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            _lib.check(lib.zk_cache_clear())
+            plan = None
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_groth16
@@ -883,6 +903,8 @@ def main():
     # ---- CPU baseline: reference-shaped pure-Python path on a bounded sample, on rank 0's host cores (for N > 1 the sample and the
     # C line are rank 0's chunk of the workload; the other ranks wait at the closing barrier)
     cpu = None
+    if plan is None:
+        plan = MsmPlan(_lib.GROUP_G1, n)
     if args.cpu_sample and rank == 0:
         cpu = cpu_baseline_msm(args, plan, scalars, points, d_scalars, d_points, n, stream, None if dist_on else result)
     if rank == 0:

@@ -148,7 +148,9 @@ int zk_ntt_fr(uint64_t *data /* n*4, in place, HOST */, unsigned log_n, int inve
  * elements are not kept: their plan lives for the call; what a thread retains is bounded by three MSM size classes per group of at
  * most 2^20 points and six NTT plans of at most 2^22 elements -- a few GB of HBM in the worst case, returned by zk_cache_clear or at
  * thread exit).  zk_cache_clear drops the calling thread's cache (device memory is
- * returned); zk_cache_stats reports {NTT plans built, NTT cache hits, MSM plans built, MSM cache hits} of the calling thread. */
+ * returned); zk_cache_stats reports {NTT plans built, NTT cache hits, MSM plans built, MSM cache hits} of the calling thread --
+ * a call beyond the cached sizes counts as one more plan BUILT every time, so a caller that sees the builds grow with its calls is
+ * on the uncached path and should hold a plan of its own (zk_msm_plan_create / zk_ntt_plan_create). */
 int zk_cache_clear(void);
 int zk_cache_stats(uint64_t out[4]);
 

@@ -7,6 +7,7 @@
 // reduce) are the generic ones of msm_impl.h run with W = 1, nb = 2^19; this header adds the table builder, the digit
 // kernel and a partition kernel for 2048 cells per window.
 #pragma once
+#include <stdlib.h>
 #include "msm_impl.h"
 
 namespace zk {
@@ -143,13 +144,25 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_prepare_kernel(const uint32
     }
 }
 
+// Measurement aid (profiles/r05_experiments.md): with ZK_MSM_ALIAS_TABLE_LOG=k in the environment every table index is folded onto the
+// first 2^k entries of the table, so that the accumulate kernel's gathers stay inside a cache-sized window -- the RESULT is then
+// garbage, the kernel's time says what the gathers from the full table cost.  Unset (always, outside that experiment): no effect.
+inline uint32_t fixed_alias_mask() {
+    static const uint32_t mask = [] {
+        const char *e = getenv("ZK_MSM_ALIAS_TABLE_LOG");
+        const int k = e ? atoi(e) : 0;
+        return (k > 0 && k < 31) ? ((1u << k) - 1u) : 0xffffffffu;
+    }();
+    return mask;
+}
+
 // One workgroup = 1024 * PPT consecutive entries of the flat (window-major) digit array.  Ranks them by cell in LDS, reserves
 // the cells' spans and writes the entries out cell by cell; the stored index is the TABLE row  w * stride + first + i
 // (| sign << 31), so the generic accumulate kernel gathers straight from the table.  With 2048 cells a workgroup's share
 // of a cell is only entries / 2048 long: PPT = 8 (8192 entries) gives 16-byte runs and half the cursor atomics of PPT = 4.
 template <int PPT, int C>
 __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int32_t *__restrict__ digits, SortBufs B, uint32_t n_pad, size_t stride,
-                                                                     uint32_t first, uint32_t total) {
+                                                                     uint32_t first, uint32_t total, uint32_t alias_mask /* 0xffffffff; see fixed_alias_mask() */) {
     constexpr int NE = PREP_NT * PPT;
     constexpr uint32_t FIX_G = FixCfg<C>::G;
     constexpr int CPT = FIX_G > PREP_NT ? (int)(FIX_G / PREP_NT) : 1;   // cells per thread (threads past the last cell hold none)
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(PREP_NT) void msm_fixed_partition_kernel(const int3
             const uint32_t p = hist[cellg] + rk[rep];
             const uint32_t v = v0 + t + rep * PREP_NT, w = v / n_pad, i = v - w * n_pad;   // a workgroup may straddle two rows
             const size_t row = (size_t)w * stride + first + i;
-            stage_idx[p] = (uint32_t)row | (dd[rep] < 0 ? 0x80000000u : 0u);
+            stage_idx[p] = ((uint32_t)row & alias_mask) | (dd[rep] < 0 ? 0x80000000u : 0u);
             stage_loc[p] = (uint8_t)(jj[rep] & (SEG_BUCKETS - 1));
             stage_cell[p] = (uint16_t)cellg;
         }

@@ -1003,7 +1003,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         constexpr int FIX_PPT = 8;
         const uint32_t fix_total = (uint32_t)FIX_W * n_pad;
         hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT, FIX_C>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
-                           L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total);
+                           L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total, fixed_alias_mask());
         hipLaunchKernelGGL((msm_cellsort_kernel<0>), dim3(FIX_G, 1), dim3(CS_NT), 0, ls, B, FIX_NB);
         hipLaunchKernelGGL((msm_segcount_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, ls, B);
         hipLaunchKernelGGL((msm_segscatter_kernel<0>), dim3(SEG_Z, SEG_LIST), dim3(SEG_NT), 0, ls, B, FIX_NB, (uint32_t)FIX_G);

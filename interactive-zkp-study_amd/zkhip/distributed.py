@@ -325,6 +325,8 @@ class DistNtt:
     # the NATURAL order is wanted across ranks -- rank r holding the contiguous slice [r n/R, (r+1) n/R) -- it is one more
     # all-to-all of n/R^2 elements per pair and a local transpose ("output order must be fixed up to
     # natural order"): BC(n1) stores X[k1 + n1 k2] at [k1 local][k2]; the natural slice of rank s is k2 in its n2/R block, all k1.
+    # These four convert a vector that already sits in a block-cyclic layout; forward / inverse (natural_in, natural_out) go from
+    # and to the natural order directly, with the transposes folded into the pass kernels' loads and stores.
     def bc_out_to_natural(self, y):
         """(k, n2, 4) BC(n1) block (what forward() returns) -> (n/R, 4): this rank's contiguous slice of the natural order."""
         R, k, c, n1 = self.world, self.k, self.c, self.n1
@@ -355,12 +357,24 @@ class DistNtt:
 
     def forward(self, x, natural_in=False, natural_out=False):
         """x: (c, n1, 4) int64 tensor, this rank's BC(n2) block (transformed in place as scratch) -> (k, n2, 4), its
-        BC(n1) block of the transform.  On one rank the layouts may also be the natural order (x[j] at j in, X[k] at k
-        out; any shape with n elements): the transposes that takes are the same first loads / last stores."""
+        BC(n1) block of the transform.
+        natural_in: x is the rank's contiguous slice x[r n/R .. (r+1) n/R) of the natural order instead (any shape with n/R
+        elements); natural_out: the result is the rank's contiguous slice of X, (n/R, 4).  Across ranks each of the two costs
+        one more all-to-all: the index the LAST local transform runs over is the high part of the output index
+        (k = k1 + n1 k2), so the rank that holds a k1 holds a strided set whatever the factorisation -- a contiguous slice
+        needs a second exchange.  What round 5 removed are the passes around it: the transposes happen in the pass kernels'
+        first loads / last stores (ZK_NTT_TRANSPOSED: the stores of the last pass ARE the send buffer, block s of it bound for
+        rank s), and one strided copy orders the received blocks.  On one rank nothing is exchanged."""
         R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
-        if (natural_in or natural_out) and (R != 1 or not getattr(self.local, "fused", False)):
-            raise ValueError("DistNtt: natural-order input / output is offered on one rank with the GPU kernels only")
-        if getattr(self.local, "fused", False):
+        fused = getattr(self.local, "fused", False)
+        if (natural_in or natural_out) and R == 1 and not fused:
+            raise ValueError("DistNtt: on one rank natural-order input / output is offered with the GPU kernels only")
+        if natural_in and R > 1:
+            send = x.reshape(k, R, c, 4).permute(1, 0, 2, 3).contiguous()   # rows j1 of this rank's block: [s][j1 local][j2 local of s]
+            x = self._exchange(send)                                        # [r][j1 local of r][j2 local]  ==  [j1][j2 local]: transposed BC(n2)
+            if not fused:
+                x = x.view(n1, c, 4).permute(1, 0, 2).contiguous()          # [j2 local][j1]
+        if fused:
             import torch
             from ._lib import NTT_BLOCKED_TW, NTT_PLAIN, NTT_TRANSPOSED
             send = torch.empty((R, c, k, 4), dtype=x.dtype, device=x.device)
@@ -368,22 +382,31 @@ class DistNtt:
             recv = self._exchange(send)                                   # [r][c][k1 local]  ==  [j2][k1 local]
             rows = x.view(-1)[:k * n2 * 4].view(k, n2, 4) if x.numel() == k * n2 * 4 else torch.empty((k, n2, 4), dtype=x.dtype, device=x.device)
             self.local.io(2, recv, rows, k, False, NTT_TRANSPOSED, NTT_TRANSPOSED if natural_out else NTT_PLAIN)
-            return rows
+            if natural_out and R > 1:                                     # rows holds [k2][k1 local]: block s = the k2 of rank s
+                got = self._exchange(rows.view(R, c, k, 4))               # [r][k2 local][k1 local of r]
+                return got.permute(1, 0, 2, 3).contiguous().view(c * n1, 4)   # [k2 local][k1]: index k1 + n1 k2
+            return rows.view(-1, 4) if natural_out else rows
         self.local.ntt_rows(x, 1, False)                              # [c][j1] -> [c][k1]
         self.local.twiddle(x, self.rank * c, False)                   # * w_n^(j2 k1), j2 = rank*c + c_local
         send = x.view(c, R, k, 4).permute(1, 0, 2, 3).contiguous()    # [s][c][k1 local of s]
         recv = self._exchange(send)                                   # [r][c][k1 local]  ==  [j2][k1 local]
         rows = recv.view(n2, k, 4).permute(1, 0, 2).contiguous()      # [k1 local][j2]
         self.local.ntt_rows(rows, 2, False)                           # [k1 local][k2]
-        return rows
+        return self.bc_out_to_natural(rows) if natural_out else rows
 
     def inverse(self, y, natural_in=False, natural_out=False):
         """y: (k, n2, 4), a BC(n1) block (used as scratch) -> (c, n1, 4), the BC(n2) block of the inverse transform
-        (1/n included).  natural_in / natural_out: as in forward."""
+        (1/n included).  natural_in / natural_out: as in forward (contiguous slices of X in, of x out)."""
         R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
-        if (natural_in or natural_out) and (R != 1 or not getattr(self.local, "fused", False)):
-            raise ValueError("DistNtt: natural-order input / output is offered on one rank with the GPU kernels only")
-        if getattr(self.local, "fused", False):
+        fused = getattr(self.local, "fused", False)
+        if (natural_in or natural_out) and R == 1 and not fused:
+            raise ValueError("DistNtt: on one rank natural-order input / output is offered with the GPU kernels only")
+        if natural_in and R > 1:
+            send = y.reshape(c, R, k, 4).permute(1, 0, 2, 3).contiguous()   # [s][k2 local][k1 local of s]
+            y = self._exchange(send)                                        # [r][k2 local of r][k1 local]  ==  [k2][k1 local]: transposed BC(n1)
+            if not fused:
+                y = y.view(n2, k, 4).permute(1, 0, 2).contiguous()          # [k1 local][k2]
+        if fused:
             import torch
             from ._lib import NTT_BLOCKED_TW, NTT_PLAIN, NTT_TRANSPOSED
             send = torch.empty((R, c, k, 4), dtype=y.dtype, device=y.device)     # [s][c local of s][k1 local]
@@ -391,11 +414,14 @@ class DistNtt:
             recv = self._exchange(send)                                   # [r][c][k1 local of r]: the blocked layout of [c][k1]
             cols = y.view(-1)[:c * n1 * 4].view(c, n1, 4)
             self.local.io(1, recv, cols, c, True, NTT_BLOCKED_TW, NTT_TRANSPOSED if natural_out else NTT_PLAIN, k.bit_length() - 1, self.rank * c)
-            return cols                                                   # * w_n^(-j2 k1), then [c][j1]   (1/n1 applied)
+            if natural_out and R > 1:                                     # cols holds [j1][j2 local]: block s = the j1 of rank s
+                got = self._exchange(cols.view(R, k, c, 4))               # [r][j1 local][j2 local of r]
+                return got.permute(1, 0, 2, 3).contiguous().view(k * n2, 4)   # [j1 local][j2]: index j1 n2 + j2
+            return cols.view(-1, 4) if natural_out else cols              # * w_n^(-j2 k1), then [c][j1]   (1/n1 applied)
         self.local.ntt_rows(y, 2, True)                               # [k1 local][k2] -> [k1 local][j2]   (1/n2 applied)
         send = y.view(k, R, c, 4).permute(1, 2, 0, 3).contiguous()    # [s][c local of s][k1 local]
         recv = self._exchange(send)                                   # [r][c][k1 local of r]
         cols = recv.permute(1, 0, 2, 3).contiguous().view(c, n1, 4)   # [c][k1]
         self.local.twiddle(cols, self.rank * c, True)                 # * w_n^(-j2 k1)
         self.local.ntt_rows(cols, 1, True)                            # [c][j1]          (1/n1 applied)
-        return cols
+        return self.bc_in_to_natural(cols) if natural_out else cols

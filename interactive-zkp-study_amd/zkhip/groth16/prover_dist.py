@@ -45,7 +45,8 @@ class DistScaleCRS:
     """This rank's share of the CRS (see the module header).  Every rank computes the exponent vectors (cheap F_r vector work);
     the fixed-base batches -- the expensive part of key generation -- and the stored points cover the rank's slices only."""
 
-    def __init__(self, circuit, alpha, beta, gamma, delta, x_val, group=None):
+    def __init__(self, circuit, alpha, beta, gamma, delta, x_val, group=None, keep_toxic=False):
+        """keep_toxic: keep the toxic waste on the object (tests only; see ScaleCRS)."""
         import torch
         import torch.distributed as dist
         self.circuit, self.group = circuit, group
@@ -53,12 +54,13 @@ class DistScaleCRS:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         m, W, Rk, rank = circuit.m, circuit.num_wires, self.world, self.rank
         al, be, ga, de, x = (v % R for v in (alpha, beta, gamma, delta, x_val))
-        self.toxic = dict(alpha=al, beta=be, gamma=ga, delta=de, x=x)
+        if keep_toxic:
+            self.toxic = dict(alpha=al, beta=be, gamma=ga, delta=de, x=x)
         self.dn = DistNtt(circuit.log_m, group=group)
         n1, n2, c, k = self.dn.n1, self.dn.n2, self.dn.c, self.dn.k
         self.cn = c * n1                                                   # coefficients (and evaluations: k * n2, the same number) per rank
         st = torch.cuda.current_stream().cuda_stream
-        ex = crs_exponents(circuit, al, be, de, x, st)
+        ex = crs_exponents(circuit, al, be, de, x)
         bc2 = lambda full: full.view(n1, n2, 4)[:, rank * c:(rank + 1) * c].transpose(0, 1).contiguous().view(self.cn, 4)   # [j2 local][j1]
         lib = _lib.load()
         g1, g2 = g1_to_limbs([G1]), g2_to_limbs([G2])

@@ -53,14 +53,16 @@ def _run_pointers(lens):
     return ptr, runs
 
 
-def _transposed_times(csr, num_wires, d_vec, stream):
+def _transposed_times(csr, num_wires, d_vec):
     """M^T v on the device for one R1CS matrix M (m x W, CSR on the host) and a device vector v of m elements: the per-wire sums
     sum_k M[k][i] v[k].  The transpose is a stable sort of the entries by column (torch index work; the values keep their limb
     form).  zk_fr_spmv_dev gives a row to ONE thread, and a wire such as `one` may sit in every constraint -- a row of 2^20 entries
     took 0.7 s -- so the entries of a wire are cut into runs of at most SPLIT (first product: one partial sum per run), and all-ones
-    matrices then add the partial sums up, again at most SPLIT per thread, level by level until one sum per wire is left."""
+    matrices then add the partial sums up, again at most SPLIT per thread, level by level until one sum per wire is left.
+    Runs on torch's current stream (the temporaries of the loop are recycled by the caching allocator in that stream's order)."""
     import torch
     from ..device import fr_spmv
+    stream = torch.cuda.current_stream().cuda_stream
     row_ptr, col, vals = csr
     m = row_ptr.shape[0] - 1
     dev = d_vec.device
@@ -96,7 +98,7 @@ def _transposed_times(csr, num_wires, d_vec, stream):
             return cur
 
 
-def crs_exponents(circuit, alpha, beta, delta, x, stream):
+def crs_exponents(circuit, alpha, beta, delta, x):
     """The discrete logarithms of the CRS queries (zkp/groth16/setup.py:18-60 over the roots-of-unity QAP) as DEVICE vectors,
     produced by the F_r vector kernels and never visiting the host:
         w^k                       zk_fr_scale_powers_dev on a vector of ones
@@ -105,8 +107,11 @@ def crs_exponents(circuit, alpha, beta, delta, x, stream):
         A_i(x), B_i(x), C_i(x)    the TRANSPOSED sparse R1CS matrices times L (zk_fr_spmv_dev, _transposed_times)
         lq[i]                     (beta A_i + alpha B_i + C_i)(x) / delta, zero at the public wires (setup.py:42-54)
         powers[j] = x^j,  hq[k] = x^k Z(x) / delta for k < m - 1 and 0 for k = m - 1 (setup.py:18-23, 56-60, 65-69)
-    -> dict(powers (m, 4), lq (W, 4), hq (m, 4), qap {"A" | "B" | "C": (W, 4)}, Zx)."""
+    -> dict(powers (m, 4), lq (W, 4), hq (m, 4), qap {"A" | "B" | "C": (W, 4)}, Zx).
+    Everything runs on torch's CURRENT stream: the torch temporaries in here are allocated and freed on it, so kernels launched on
+    any other stream could still be reading a block the caching allocator has already handed out again."""
     import torch
+    stream = torch.cuda.current_stream().cuda_stream
     m, W = circuit.m, circuit.num_wires
     zx = (pow(x, m, R) - 1) % R
     if zx == 0 or delta == 0:
@@ -131,7 +136,7 @@ def crs_exponents(circuit, alpha, beta, delta, x, stream):
     FrVec.mul(lag.data_ptr(), pre.data_ptr(), suf[1:].data_ptr(), m, stream)
     FrVec.mul(lag.data_ptr(), lag.data_ptr(), roots.data_ptr(), m, stream)
     FrVec.lincomb(lag.data_ptr(), [lag.data_ptr()], [zx * pow(m, -1, R) % R * pow(total, -1, R) % R], m, stream=stream)   # L_k(x)
-    qap = {name: _transposed_times(csr, W, lag, stream) for name, csr in circuit.r1cs_csr().items()}   # M_i(x) = sum_k M[k][i] L_k(x)
+    qap = {name: _transposed_times(csr, W, lag) for name, csr in circuit.r1cs_csr().items()}   # M_i(x) = sum_k M[k][i] L_k(x)
     lq = new(W)
     FrVec.lincomb(lq.data_ptr(), [qap[k].data_ptr() for k in "ABC"], [beta * dinv % R, alpha * dinv % R, dinv], W, stream=stream)
     lq[torch.from_numpy(np.array(circuit.pub, dtype=np.int64)).cuda()] = 0
@@ -153,16 +158,19 @@ class ScaleCRS:
     come from crs_exponents (F_r vector kernels) and the points from the fixed-base batch kernels on device buffers
     (zk_fixed_base_g1_dev / _g2_dev): 0.1 s for 2^20 constraints where the Python loops took 3.5 s."""
 
-    def __init__(self, circuit, alpha, beta, gamma, delta, x_val):
+    def __init__(self, circuit, alpha, beta, gamma, delta, x_val, keep_toxic=False):
+        """keep_toxic: keep the toxic waste and the exponent vectors (the discrete logarithms of the queries) on the object -- for
+        tests that check the key against closed forms; a key generator drops them (as DeviceSRS.generate does with tau)."""
         import torch
         self.circuit = circuit
         m, W = circuit.m, circuit.num_wires
         al, be, ga, de, x = (v % R for v in (alpha, beta, gamma, delta, x_val))
-        self.toxic = dict(alpha=al, beta=be, gamma=ga, delta=de, x=x)
         lib = _lib.load()
         st = torch.cuda.current_stream().cuda_stream
-        ex = crs_exponents(circuit, al, be, de, x, st)
-        self.Zx, self.d_qap, self.d_l_scalars = ex["Zx"], ex["qap"], ex["lq"]
+        ex = crs_exponents(circuit, al, be, de, x)
+        if keep_toxic:
+            self.toxic = dict(alpha=al, beta=be, gamma=ga, delta=de, x=x)
+            self.Zx, self.d_qap, self.d_l_scalars = ex["Zx"], ex["qap"], ex["lq"]
         # sigma1_1 / sigma2_1 (setup.py:15-16, 62-63)
         self.sigma1_1 = fixed_base_mul(G1, [al, be, de])
         self.sigma2_1 = fixed_base_mul(G2, [be, ga, de])

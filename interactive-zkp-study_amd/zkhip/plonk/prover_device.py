@@ -294,8 +294,10 @@ class DevicePlonk:
         return pp
 
     # ---- the five rounds ---------------------------------------------------------------------------------------
-    def prove(self, a_vals, b_vals, c_vals, blinding=None):
-        """a_vals, b_vals, c_vals: (n, 4) limb arrays or device tensors of the wire columns -> Proof."""
+    def prove(self, a_vals, b_vals, c_vals, blinding=None, challenges=None):
+        """a_vals, b_vals, c_vals: (n, 4) limb arrays or device tensors of the wire columns -> Proof.  blinding (nine scalars) and
+        challenges ({"beta": .., "gamma": ..} in place of those two transcript values) exist for the tests that compare this
+        prover with the oracle field by field; a caller leaves both None."""
         torch = _torch()
         n, size, step, fv, st = self.n, self.size, self.step, self.fv, self.st
         blind = list(blinding) if blinding is not None else [secrets.randbelow(R) for _ in range(9)]
@@ -318,6 +320,8 @@ class DevicePlonk:
 
         # round 2 (round2.py:50-86, permutation.py:89-137)
         beta, gamma = tr.challenge_scalar(b"beta"), tr.challenge_scalar(b"gamma")
+        if challenges:
+            beta, gamma = FR(challenges.get("beta", int(beta))), FR(challenges.get("gamma", int(gamma)))
         be, ga = int(beta), int(gamma)
         z_ev = self._accumulator(cols, be, ga)
         z = self._blinded(self._interpolate(z_ev, B["z"]), blind[6:9])

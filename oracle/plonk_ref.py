@@ -351,6 +351,9 @@ def round2(st):
     """round2.py:50-86."""
     st.beta = st.transcript.challenge_scalar(b"beta")
     st.gamma = st.transcript.challenge_scalar(b"gamma")
+    if st.challenges:                                  # tests only: a chosen beta / gamma (the transcript has absorbed its own all the same)
+        st.beta = st.challenges.get("beta", st.beta) % R
+        st.gamma = st.challenges.get("gamma", st.gamma) % R
     n = st.n
     z_evals = compute_accumulator(st.a_vals, st.b_vals, st.c_vals, st.pp.sigma, n, st.pp.domain, st.beta, st.gamma)
     z_poly = from_evaluations(z_evals, st.omega)
@@ -452,9 +455,12 @@ def round5(st):
     pf.W_zeta_omega_comm = commit(w_zeta_omega, st.srs)
 
 
-def prove(circuit, a_vals, b_vals, c_vals, public_inputs, preprocessed, srs, blinding, return_state=False):
-    """prover/__init__.py:158-211 with the 9 blinding scalars injected (draw order: a a b b c c z z z)."""
+def prove(circuit, a_vals, b_vals, c_vals, public_inputs, preprocessed, srs, blinding, return_state=False, challenges=None):
+    """prover/__init__.py:158-211 with the 9 blinding scalars injected (draw order: a a b b c c z z z).  challenges: {"beta": ..,
+    "gamma": ..} replaces those two Fiat-Shamir values (tests of the grand product's zero-denominator rows; the reference draws
+    them from the transcript only)."""
     st = State()
+    st.challenges = challenges
     st.a_vals, st.b_vals, st.c_vals = ([v % R for v in col] for col in (a_vals, b_vals, c_vals))
     st.public_inputs, st.pp, st.srs = public_inputs, preprocessed, srs
     st.transcript = Transcript()

@@ -72,6 +72,13 @@ def _worker(rank, world, port, log_n, l1, ret):
         back = d.inverse(y)
         ok_i = np.array_equal(back.numpy().view(np.uint64), d.scatter_in(full))
         ok_i = ok_i and np.array_equal(d.bc_in_to_natural(back).numpy().view(np.uint64), full[rank * per:(rank + 1) * per])
+        # the transforms themselves from and to the natural order across the ranks (contiguous slices in, contiguous slices out)
+        fwd_nat = d.forward(x_nat.clone(), natural_in=True, natural_out=True)
+        ok_n = ok_n and np.array_equal(fwd_nat.numpy().view(np.uint64).reshape(-1, 4), want[rank * per:(rank + 1) * per])
+        inv_nat = d.inverse(fwd_nat, natural_in=True, natural_out=True)
+        ok_i = ok_i and np.array_equal(inv_nat.numpy().view(np.uint64).reshape(-1, 4), full[rank * per:(rank + 1) * per])
+        mixed = d.forward(torch.from_numpy(d.scatter_in(full).view(np.int64)), natural_out=True)       # block-cyclic in, natural out
+        ok_n = ok_n and np.array_equal(mixed.numpy().view(np.uint64).reshape(-1, 4), want[rank * per:(rank + 1) * per])
         ret[rank] = (bool(ok_f and ok_n), bool(ok_i))
     finally:
         dist.destroy_process_group()

@@ -170,6 +170,16 @@ def _worker(rank, world, port, log_n, l1, ret):
         back = d.inverse(y)
         ok_i = np.array_equal(back.cpu().numpy().view(np.uint64), d.scatter_in(full))
         ok_i = ok_i and np.array_equal(d.bc_in_to_natural(back).cpu().numpy().view(np.uint64), full[rank * per:(rank + 1) * per])
+        # natural order in and out with the transposes inside the pass kernels (ZK_NTT_TRANSPOSED stores = the send buffer)
+        x_nat = torch.from_numpy(full[rank * per:(rank + 1) * per].copy().view(np.int64)).cuda()
+        fwd_nat = d.forward(x_nat.clone(), natural_in=True, natural_out=True)
+        ok_f = ok_f and np.array_equal(fwd_nat.cpu().numpy().view(np.uint64).reshape(-1, 4), want[rank * per:(rank + 1) * per])
+        inv_nat = d.inverse(fwd_nat, natural_in=True, natural_out=True)
+        ok_i = ok_i and np.array_equal(inv_nat.cpu().numpy().view(np.uint64).reshape(-1, 4), full[rank * per:(rank + 1) * per])
+        mixed = d.forward(torch.from_numpy(d.scatter_in(full).view(np.int64)).cuda(), natural_out=True)
+        ok_f = ok_f and np.array_equal(mixed.cpu().numpy().view(np.uint64).reshape(-1, 4), want[rank * per:(rank + 1) * per])
+        mixed_i = d.inverse(torch.from_numpy(d.scatter_out(want).view(np.int64)).cuda(), natural_out=True)
+        ok_i = ok_i and np.array_equal(mixed_i.cpu().numpy().view(np.uint64).reshape(-1, 4), full[rank * per:(rank + 1) * per])
         ret[rank] = (bool(ok_f), bool(ok_i))
     finally:
         dist.destroy_process_group()

@@ -154,6 +154,64 @@ def test_ntt_2pow22_bit_exact_vs_oracle(L):
     assert np.array_equal(d.cpu().numpy().view(np.uint64), co.ntt_arr(X, o.get_root_of_unity(n), False))
 
 
+def test_ntt_2pow24_bit_exact_vs_oracle():
+    """north_star's target size in full: all 2^24 outputs of the forward AND of the inverse transform against the oracle's
+    recursive radix-2 NTT (8 + 8 + 8 digit split; polynomial.py:316-378 at a size the reference itself cannot reach)."""
+    import torch
+    L = 24
+    n = 1 << L
+    X = _fast_rand(np.random.default_rng(2424), n)
+    w = o.get_root_of_unity(n)
+    st = torch.cuda.current_stream().cuda_stream
+    plan = NttPlan(L)
+    for inverse in (False, True):
+        d = torch.from_numpy(X.view(np.int64).copy()).cuda()
+        plan.run(d.data_ptr(), inverse, None, st)
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), co.ntt_arr(X, w, inverse)), inverse
+        del d
+    plan.close()
+
+
+def _scale_by_powers(X, k):
+    """x_i * k^i mod r on the host (Python integers, blocks of 2^16 with a running power): the coset scaling of
+    zkp/plonk/utils.py:145-176, independent of both the library and the C oracle."""
+    out = np.empty_like(X)
+    blk = 1 << 16
+    kb = pow(k, blk, o.R)
+    base = 1
+    pw = [1] * blk
+    for i in range(1, blk):
+        pw[i] = pw[i - 1] * k % o.R
+    for lo in range(0, X.shape[0], blk):
+        xs = co.from_limbs(X[lo:lo + blk])
+        out[lo:lo + blk] = co.to_limbs([v * p % o.R * base % o.R for v, p in zip(xs, pw)])
+        base = base * kb % o.R
+    return out
+
+
+@pytest.mark.parametrize("L,k", [(20, 5), (20, 0x1D0F4C0FFEE), (22, 5), (22, 7)])
+def test_coset_ntt_large_vs_oracle(L, k):
+    """coset_fft / coset_ifft (utils.py:145-205) at the sizes the provers run them (PLONK's 4n-point quotient domain at 2^20 gates
+    is 2^22), every output against the oracle: forward = the oracle's NTT of the host-scaled input; inverse = the host-unscaled
+    oracle inverse NTT.  (Up to 2^17 in test_coset_ntt_vs_oracle; beyond that only through whole proofs until round 5.)"""
+    import torch
+    n = 1 << L
+    X = _fast_rand(np.random.default_rng(4000 + L + k % 97), n)
+    w = o.get_root_of_unity(n)
+    st = torch.cuda.current_stream().cuda_stream
+    plan = NttPlan(L)
+    d = torch.from_numpy(X.view(np.int64).copy()).cuda()
+    plan.run(d.data_ptr(), False, k, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), co.ntt_arr(_scale_by_powers(X, k), w))
+    d = torch.from_numpy(X.view(np.int64).copy()).cuda()
+    plan.run(d.data_ptr(), True, k, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), _scale_by_powers(co.ntt_arr(X, w, True), pow(k, -1, o.R)))
+    plan.close()
+
+
 def test_ntt_maximum_domain_2pow28_round_trip():
     """The largest domain the reference admits (get_root_of_unity: n <= 2^28, zkp/plonk/field.py:169-172): forward + inverse
     restores all 2^28 elements, and one output is checked against the closed form of a two-term polynomial."""

@@ -148,6 +148,79 @@ def test_device_prover_matches_fixture(setup):
     assert pl.verify(_as_oracle_proof(got), opub, pl.preprocess(ocirc, osrs), osrs) is True
 
 
+def _oracle_circuit_n64(which):
+    """Two 64-gate circuits in the oracle's plain-int form (built with the reference's gate API, circuit.py:116-161): `chain` alternates
+    multiplication and addition gates, each output wired to the next left input; `mixed` adds constant gates, a value fanned out to
+    several right inputs and a tail of unwired gates."""
+    import numpy as np
+    rng = np.random.default_rng(64 if which == "chain" else 65)
+    c = pl.Circuit()
+    a, b, cc = [], [], []
+    cur = int(rng.integers(2, 1 << 40))
+    shared = int(rng.integers(2, 1 << 40))
+    for i in range(64):
+        kind = i % 2 if which == "chain" else (i * 7 + 3) % 3
+        y = shared if (which == "mixed" and i % 5 == 0) else int(rng.integers(1, 1 << 40))
+        if kind == 0:
+            g, out = c.add_multiplication_gate(), cur * y % R
+        elif kind == 1:
+            g, out = c.add_addition_gate(), (cur + y) % R
+        else:
+            k = int(rng.integers(1, 1 << 30))
+            g, out, y = c.add_constant_gate(k), (cur + k) % R, 0
+        a.append(cur); b.append(y); cc.append(out)
+        if i and not (which == "mixed" and i >= 56):
+            c.add_copy_constraint(g - 1, 2, g, 0)              # previous output -> this left input
+        if which == "mixed" and i % 5 == 0 and i and kind != 2:
+            c.add_copy_constraint(0, 1, g, 1)                  # the shared right input
+        cur = out
+    assert pl.gates_satisfied(c, a, b, cc)
+    return c, a, b, cc
+
+
+@pytest.mark.parametrize("which,zero_row", [("chain", None), ("mixed", None), ("chain", 20), ("mixed", 63)])
+def test_device_prover_equals_oracle_at_n64(which, zero_row):
+    """DevicePlonk against oracle/plonk_ref.py (the reference's O(n^2) shape: coefficient products, long division by Z_H, one ec_mul per
+    commitment term) at n = 64, all 16 proof fields and the 8 preprocessing commitments -- nothing here is compared with another
+    part of the library.  zero_row: beta / gamma chosen so that this row of the grand product has a zero denominator
+    (permutation.py:118-135 with py_ecc's x / 0 = 0; on the last row the reference never divides): the two provers must then
+    behave alike -- the same proof, or both refuse because the constraint polynomial is no longer divisible by Z_H."""
+    import c_oracle as co
+    ocirc, a, b, c = _oracle_circuit_n64(which)
+    n = 64
+    osrs = o.srs_generate(n + 6, 7)
+    opp = pl.preprocess(ocirc, osrs)
+    assert opp.n == n
+    blinding = [31337 + 101 * i for i in range(9)]
+    challenges = None
+    if zero_row is not None:
+        s1 = pl.build_permutation_polynomials(opp.sigma, n, opp.domain)[0]
+        beta = 0xB37A5EED
+        challenges = {"beta": beta, "gamma": (-(a[zero_row] + beta * s1[zero_row])) % R}
+    limbs = lambda vals: _lib.ints_to_limbs([int(v) % R for v in vals])
+    sel = [limbs(col) for col in ocirc.get_selector_polynomials()]
+    sig = [limbs(col) for col in pl.build_permutation_polynomials(opp.sigma, n, opp.domain)]
+    dev = DevicePlonk(sel, sig, co.g1_to_arr(osrs[0]))
+    dpp = dev.preprocessed()
+    for k in ("q_l", "q_r", "q_o", "q_m", "q_c", "s_sigma1", "s_sigma2", "s_sigma3"):
+        got = getattr(dpp, k + "_comm")
+        assert (None if got is None else (int(got[0]), int(got[1]))) == getattr(opp, k + "_comm"), k
+    try:
+        want = pl.prove(ocirc, a, b, c, [], opp, osrs, blinding, challenges=challenges)
+    except ValueError:
+        want = None
+    if want is None:
+        assert zero_row is not None                                     # an ordinary proof must exist
+        with pytest.raises(ValueError):
+            dev.prove(limbs(a), limbs(b), limbs(c), blinding=blinding, challenges=challenges)
+        return
+    got = _as_oracle_proof(dev.prove(limbs(a), limbs(b), limbs(c), blinding=blinding, challenges=challenges))
+    for f in pl.PROOF_FIELDS:
+        assert getattr(got, f) == getattr(want, f), f
+    if zero_row is None:
+        assert pl.verify(got, [], opp, osrs) is True
+
+
 def test_unsatisfied_witness_is_refused_like_the_reference(setup):
     """round3.py:140-147 raises when C is not divisible by Z_H; so do the oracle and both backends."""
     case, srs, circuit, pp, cols = setup
