@@ -1,7 +1,9 @@
 // api.hip -- the extern "C" surface of libzkhip.so (declared in include/zkhip.h).
 #include <string.h>
+#include <array>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include "common.h"
 #include "curve.h"
@@ -23,6 +25,25 @@ int require_device() {
         return ZK_ERR_NO_DEVICE;
     }
     return ZK_OK;
+}
+
+// msm.h: the process-wide pool of lane streams, four per device, created together on first use (under a lock: plans may be
+// created from several threads) and left to the runtime at process exit.
+hipStream_t lane_stream(int device, int group, int lane) {
+    static std::mutex mu;
+    static std::map<int, std::array<hipStream_t, 4>> pools;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pools.find(device);
+    if (it == pools.end()) {
+        int cur = -1;
+        ZK_HIP(hipGetDevice(&cur));
+        if (cur != device) ZK_HIP(hipSetDevice(device));
+        std::array<hipStream_t, 4> p{};
+        for (auto &st : p) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if (cur != device) ZK_HIP(hipSetDevice(cur));
+        it = pools.emplace(device, p).first;
+    }
+    return it->second[(size_t)(lane + (group == ZK_GROUP_G2 ? 3 : 0)) & 3u];
 }
 
 // Plans own device memory, streams and (NTT) a per-device kernel attribute: they work on the device they were created on only.

@@ -25,6 +25,16 @@ struct MsmPlanBase {
     virtual int bind_points(const void *d_points, size_t n, hipStream_t st) = 0;
     virtual int submit_bound(const void *d_scalars, size_t first, size_t n, hipStream_t st) = 0;
 };
+// The streams the lanes of ALL plans run on: four per device, created together the first time a plan needs one and never destroyed.
+// Why a pool: the HIP runtime spreads streams over its (by default four) hardware queues in creation order, and which of a prover's
+// MSMs end up sharing a queue decides how their kernels interleave -- the same Groth16 proof took 9.07 / 9.15 / 9.29 / 9.44 ms with
+// 1 / 0 / 2 / 3 unrelated streams created before the prover's plans (profiles/r05_experiments.md: the "in-process penalty" of
+// bench.py, whose secondaries create and destroy plans before the prover).  With the pool the queue a lane runs on depends on the
+// lane's index and the plan's group only: G1 lanes take streams 0 1 2, G2 lanes 3 0 1 -- the three MSMs of a Groth16 proof (two G1
+// lanes, one G2 lane) always sit on three different streams, whatever else the process has created.  Plans that share a stream
+// serialise on it; they are not in flight together in either prover.
+hipStream_t lane_stream(int device, int group, int lane);
+
 // all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use;
 // chunk_log: log2 of the chunk size for MSMs beyond it (0 = the default 2^22; zk_msm_plan_create_ex)
 MsmPlanBase *msm_plan_new_g1(size_t max_n, bool all_lanes, int chunk_log);

@@ -841,14 +841,13 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         // the memsets above were issued on the null stream, which the lane's non-blocking stream does not wait for: make sure they
         // have landed before the lane's first kernel can run (it bumps the error counter in the header zeroed here)
         ZK_HIP(hipStreamSynchronize(0));
-        ZK_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        L.stream = lane_stream(device, group, (int)(&L - lanes));
         for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         L.ready = true;
     }
     ~MsmPlanImpl() override {
         for (auto &L : lanes) {
-            if (L.stream) (void)hipStreamSynchronize(L.stream);
-            if (L.stream) (void)hipStreamDestroy(L.stream);
+            if (L.stream) (void)hipStreamSynchronize(L.stream);   // (the stream belongs to the process-wide pool: msm.h lane_stream)
             for (hipEvent_t e : {L.ev_in, L.ev_consumed, L.done})
                 if (e) (void)hipEventDestroy(e);
             for (auto &e : L.ev)

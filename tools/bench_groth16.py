@@ -64,6 +64,14 @@ def run(log_m, reps, lib_path="", circuit="chain", pipelined_only=False, warm=4)
     crs = ScaleCRS(circ, toxic["alpha"], toxic["beta"], toxic["gamma"], toxic["delta"], toxic["x"])
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
+    dummies = []
+    if os.environ.get("ZK_EXPERIMENT_DUMMY_STREAMS"):   # experiment (profiles/r05_experiments.md): k unrelated streams created before the prover's plans
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        for _ in range(int(os.environ["ZK_EXPERIMENT_DUMMY_STREAMS"])):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0
+            dummies.append(h)
     prover = ScaleProver(crs)
     dev = lambda v: torch.from_numpy(_lib.ints_to_limbs(v).view(np.int64)).cuda()
     A0, B0, C0, W0 = dev(a), dev(b), dev(c), dev(w)
