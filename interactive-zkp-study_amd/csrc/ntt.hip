@@ -16,6 +16,7 @@
 // issue-bound and the repacking adds instructions); canonical (< r) only at the first load and the last store.
 // HBM traffic: 64 bytes per element per pass; the kernel is bound by the vector-ALU issue rate (~10.5 modular
 // products per element: butterflies + one per pass boundary, and 22 modular additions / subtractions), not by bandwidth.
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #include "ntt.h"
@@ -156,7 +157,11 @@ __device__ __forceinline__ Fr io_coset(const NttIoArgs &io, uint32_t i) {
 //              stores (FINAL); the scratch between passes is always plain.  The tile carries 2^g "bystander" columns next to the
 //              digit: 2^(g - gb) adjacent ELEMENTS and 2^gb adjacent TRANSFORMS of the batch (gb > 0 only with a transposed
 //              buffer, whose memory runs along the batch index), so that both sides of a transposing pass move >= 128-byte runs.
-template <bool FINAL, bool IN_CANON, int IN_L, int OUT_L>
+//   T1K      : the tile holds 2^10 elements (the usual case): the limb planes of the tile then lie 4096 bytes apart and those of the
+//              twiddle table 1024 (the table is given 256 columns whatever the digit) -- constants the compiler folds into the
+//              LDS instructions' offsets, pairing the limb accesses of an element into ds_read2st64_b32 / ds_write2st64_b32
+//              (five LDS instructions per element instead of nine)
+template <bool FINAL, bool IN_CANON, int IN_L, int OUT_L, bool T1K = false>
 __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict__ in_v, void *__restrict__ out_v,
                                                           const Fr *__restrict__ tile_tw, const Fr *__restrict__ twA,
                                                           const Fr *__restrict__ twB, Fr scale, NttPassParams P, NttIoArgs io) {
@@ -165,8 +170,9 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     const uint32_t lp = P.lp, g = P.g, G = 1u << g;
     constexpr bool HAS_GB = (IN_L == NTT_TRANSPOSED || OUT_L == NTT_TRANSPOSED);
     const uint32_t gb = HAS_GB ? P.gb : 0u, ga = g - gb, Gb1 = (1u << gb) - 1u, Ga1 = (1u << ga) - 1u;
-    const uint32_t tile = 1u << (lp + g);
-    const uint32_t ntw = 1u << lp;
+    const uint32_t tile = T1K ? 1024u : 1u << (lp + g);
+    const uint32_t ntw = 1u << lp;                     // entries of the twiddle table,
+    const uint32_t tws = T1K ? 256u : ntw;             // and the distance of its limb planes
     uint32_t *data = lds;
     uint32_t *tw = lds + NL * tile;
     // blockIdx.y = index of the transform (of the group of 2^gb transforms) inside a batch of independent transforms
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
 
     for (uint32_t i = t + 1; i < ntw; i += NTT_NT) {
         const uint32_t st = 31u - (uint32_t)__clz((int)i), j = i - (1u << st);
-        lds_st(tw, ntw, i, tile_tw[(size_t)(j << (lp - 1 - st)) << P.tw_shift]);
+        lds_st(tw, tws, i, tile_tw[(size_t)(j << (lp - 1 - st)) << P.tw_shift]);
     }
 
     const uint32_t tile_id = blockIdx.x;
@@ -239,10 +245,10 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
         const int R = sh == 0 ? 1 : 2;
         const bool last = (sh - R + 1 == 0);
         if (R == 2) {
-            if (last) ntt_round<2, true>(data, tw, tile, ntw, lp, g, sh);
-            else ntt_round<2, false>(data, tw, tile, ntw, lp, g, sh);
+            if (last) ntt_round<2, true>(data, tw, tile, tws, lp, g, sh);
+            else ntt_round<2, false>(data, tw, tile, tws, lp, g, sh);
         } else {
-            ntt_round<1, true>(data, tw, tile, ntw, lp, g, sh);  // a single stage is only ever the last one
+            ntt_round<1, true>(data, tw, tile, tws, lp, g, sh);  // a single stage is only ever the last one
         }
         sh -= R;
         __syncthreads();
@@ -532,15 +538,29 @@ void NttPlan::run_io(const void *d_in, void *d_out, bool inverse, unsigned batch
     X(true, true, NTT_PLAIN, NTT_PLAIN) X(true, true, NTT_PLAIN, NTT_BLOCKED_TW) X(true, true, NTT_PLAIN, NTT_TRANSPOSED)      \
     X(true, true, NTT_BLOCKED_TW, NTT_PLAIN) X(true, true, NTT_TRANSPOSED, NTT_PLAIN) X(true, true, NTT_TRANSPOSED, NTT_TRANSPOSED) \
     X(true, true, NTT_BLOCKED_TW, NTT_TRANSPOSED) X(true, true, NTT_TRANSPOSED, NTT_BLOCKED_TW)
+// the plain passes of a plain transform again with T1K (2^10-element tiles)
+#define ZK_NTT_PASS_CASES_1K(X) X(false, true, NTT_PLAIN, NTT_PLAIN) X(false, false, NTT_PLAIN, NTT_PLAIN) X(true, false, NTT_PLAIN, NTT_PLAIN)
 static std::vector<const void *> pass_kernel_functions() {
     std::vector<const void *> v;
 #define X(F, C, I, O) v.push_back(reinterpret_cast<const void *>(&ntt_pass_kernel<F, C, I, O>));
     ZK_NTT_PASS_CASES(X)
 #undef X
+#define X(F, C, I, O) v.push_back(reinterpret_cast<const void *>(&ntt_pass_kernel<F, C, I, O, true>));
+    ZK_NTT_PASS_CASES_1K(X)
+#undef X
     return v;
 }
 static void launch_pass(bool fin, bool canon, int in_l, int out_l, dim3 grid, size_t lds, hipStream_t st, const void *src, void *dst, const Fr *tile_tw,
-                        const Fr *A, const Fr *B, Fr scale, const NttPassParams &P, const NttIoArgs &io) {
+                        const Fr *A, const Fr *B, Fr scale, const NttPassParams &P, const NttIoArgs &io, bool t1k) {
+    if (t1k) {
+#define X(F, C, I, O)                                                                                                                \
+    if (fin == F && canon == C && in_l == I && out_l == O) {                                                                         \
+        hipLaunchKernelGGL((ntt_pass_kernel<F, C, I, O, true>), grid, dim3(NTT_NT), lds, st, src, dst, tile_tw, A, B, scale, P, io); \
+        return;                                                                                                                      \
+    }
+        ZK_NTT_PASS_CASES_1K(X)
+#undef X
+    }
 #define X(F, C, I, O)                                                                                                          \
     if (fin == F && canon == C && in_l == I && out_l == O) {                                                                   \
         hipLaunchKernelGGL((ntt_pass_kernel<F, C, I, O>), grid, dim3(NTT_NT), lds, st, src, dst, tile_tw, A, B, scale, P, io); \
@@ -590,7 +610,9 @@ void NttPlan::launch_passes(const void *d_in, void *d_out, bool inverse, unsigne
         const void *src = first_pass ? d_in : static_cast<const void *>(tmp_.p);
         void *dst = final_pass ? d_out : tmp_.p;
         const uint32_t tile = 1u << (lp + P.g);
-        const size_t lds = ((size_t)NL * tile + (size_t)NL * (1u << lp)) * sizeof(uint32_t);
+        static const bool no_1k = getenv("ZK_NTT_NO_T1K") != nullptr;    // A/B runs of the round-5 experiment (tools/ab_ntt.py)
+        const bool t1k = !no_1k && tile == 1024 && il == NTT_PLAIN && ol == NTT_PLAIN && lp <= 8 && !(final_pass && first_pass);
+        const size_t lds = ((size_t)NL * tile + (size_t)NL * (t1k ? 256u : (1u << lp))) * sizeof(uint32_t);
         const unsigned blocks = (unsigned)(n >> (lp + P.g - P.gb));
         const dim3 grid(blocks, batch >> P.gb);
         const Fr *A = twA_[dir].as<Fr>(), *B = twB_[dir].as<Fr>();
@@ -606,7 +628,7 @@ void NttPlan::launch_passes(const void *d_in, void *d_out, bool inverse, unsigne
             for (unsigned q = 0; q < P.nmid; q++) P.lmid[q] = digits_[1 + q];
             P.apply_scale = (inverse && D == 1) ? 1 : 0;
         }
-        launch_pass(final_pass, first_pass, il, ol, grid, lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B, scale_inv_, P, io);
+        launch_pass(final_pass, first_pass, il, ol, grid, lds, st, src, dst, tile_tw_[dir].as<Fr>(), A, B, scale_inv_, P, io, t1k);
     }
 }
 

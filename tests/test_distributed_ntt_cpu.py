@@ -93,6 +93,77 @@ def test_dist_ntt_gloo(world, log_n, l1):
     assert dict(ret) == {r: (True, True) for r in range(world)}
 
 
+class NullLocal:
+    """Local transforms that do nothing: the dry run below is about the shapes and byte counts of the exchanges."""
+
+    def ntt_rows(self, t, which, inverse):
+        pass
+
+    def twiddle(self, t, row0, inverse):
+        pass
+
+
+def _dry_worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.join(HERE, "..", "interactive-zkp-study_amd"))
+    from zkhip.distributed import DistNtt, all_gather_partials
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sent = []
+        real = dist.all_to_all_single
+
+        def counting(out, inp, *a, **kw):
+            sent.append(inp.numel() * inp.element_size())
+            return real(out, inp, *a, **kw)
+        dist.all_to_all_single = counting
+        # (1) ONE transform of 2^24 points over the eight ranks: forward, inverse, and from / to the natural order
+        d = DistNtt(24, local=NullLocal())
+        n_loc = (1 << 24) // world
+        assert d.c * d.n1 == n_loc == d.k * d.n2
+        x = torch.zeros(d.local_shape_in() + (4,), dtype=torch.int64)
+        y = d.forward(x)
+        assert tuple(y.shape) == d.local_shape_out() + (4,)
+        back = d.inverse(y)
+        assert tuple(back.shape) == d.local_shape_in() + (4,)
+        nat = d.forward(torch.zeros((n_loc, 4), dtype=torch.int64), natural_in=True, natural_out=True)
+        assert tuple(nat.shape) == (n_loc, 4)
+        assert tuple(d.inverse(nat, natural_in=True, natural_out=True).shape) == (n_loc, 4)
+        per_exchange = n_loc * 32                         # every rank sends its whole block, 1/R of it to each peer
+        assert sent == [per_exchange] * (1 + 1 + 3 + 3), sent
+        del x, y, back, nat
+        # (2) the collectives of one DistScaleProver proof at 2^20 constraints (groth16/prover_dist.py prove): three inverse
+        #     transforms, three forward ones on the coset, one inverse -- one all-to-all each -- then ONE all-gather of the 64-limb partials
+        sent.clear()
+        dn = DistNtt(20, local=NullLocal())
+        cn = dn.c * dn.n1
+        assert cn == dn.k * dn.n2 == (1 << 20) // world
+        shape_ev, shape_co = (dn.k, dn.n2, 4), (dn.c, dn.n1, 4)
+        coef = [dn.inverse(torch.zeros(shape_ev, dtype=torch.int64)).reshape(cn, 4) for _ in range(3)]
+        on_coset = [dn.forward(u.view(shape_co)).reshape(cn, 4) for u in coef]
+        h = dn.inverse(on_coset[0].view(shape_ev)).reshape(cn, 4)
+        assert tuple(h.shape) == (cn, 4) and sent == [cn * 32] * 7, sent
+        mine = np.full(64, rank + 1, dtype=np.uint64)     # 16 + 16 + 32 limbs: the partials of proof_A, proof_C, proof_B
+        everyone = all_gather_partials(mine)
+        assert everyone.shape == (world, 64) and [int(v) for v in everyone[:, 0]] == list(range(1, world + 1))
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dry_run_of_every_collective_at_eight_ranks():
+    """The driver's node has eight GPUs and no builder ever had more than one: every collective of the single 2^24-point transform
+    (block-cyclic and natural order) and of a distributed Groth16 proof at 2^20 constraints, with the REAL shapes and byte counts,
+    over gloo on eight CPU ranks and local transforms that do nothing -- a shape or count that does not fit fails here, not on the
+    first eight-GPU run."""
+    world = 8
+    port = 33500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dry_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
 def test_dist_ntt_rejects_bad_world():
     sys.path.insert(0, os.path.join(HERE, "..", "interactive-zkp-study_amd"))
     from zkhip.distributed import DistNtt
