@@ -616,42 +616,45 @@ __device__ __forceinline__ Xyzz<F> sum_list(const PackedAffine<F> *__restrict__ 
     return acc;
 }
 
-template <class F> __device__ __forceinline__ Xyzz<F> shfl_down_xyzz(const Xyzz<F> &p, int delta) {
-    Xyzz<F> r;
-    constexpr int NW = sizeof(Xyzz<F>) / 4;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
-    return r;
+// Sum of the 64 points a wavefront holds one per lane, left in tree[0]: the points go to LDS and are folded in halves (tree[i] +=
+// tree[i + d], d = 32 .. 1) by teams of four lanes (curve.h team4_add: ~1300 instructions per level instead of the ~3400 of a
+// one-lane general addition; seven rounds, the first level taking two).  Round 5: until then a __shfl_down tree of one-lane
+// additions -- the general addition next to the list loop cost the G1 kernel 7 spilled registers, and these trees are a third of
+// the dependent chain a heavy bucket puts on the critical path of a blocking MSM.  One wavefront per workgroup: the lanes run in
+// lockstep, an LDS write is visible to the wavefront's later reads (s_waitcnt, no barrier).
+template <class F> __device__ __forceinline__ void wave_tree_sum(const Xyzz<F> &mine, Xyzz<F> *tree) {
+    const uint32_t lane = threadIdx.x;
+    tree[lane] = mine;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+#pragma unroll 1
+        for (uint32_t q = lane >> 2; q < d; q += 16) team4_add(lane & 3u, tree + q, tree + q + d, QuadDpp{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 }
 // Heavy buckets (lists longer than heavy_th: skewed / witness-like scalars): wavefront tasks listed by msm_rank_kernel and taken by the
 // first HEAVY_BLOCKS workgroups of the accumulate grid (round 4; a kernel of its own behind the accumulate kernel before -- its ~46
 // dependent additions then sat on the critical path of a blocking MSM: 0.3 ms in G1, 1 ms in G2 with a quarter of the scalars equal
-// to one).  A task = 64 consecutive HEAVY_SEG-entry segments of one bucket's list: every lane sums its segment, a __shfl
-// tree leaves the task's partial sum in lane 0, which stores it and counts the task as finished on its bucket; the wavefront that
-// finishes a bucket's LAST task then sums that bucket's partials (stride-64 serial sums, __shfl tree) into the bucket array.  With
+// to one).  A task = 64 consecutive HEAVY_SEG-entry segments of one bucket's list: every lane sums its segment, wave_tree_sum
+// leaves the task's partial sum in LDS, lane 0 stores it and counts the task as finished on its bucket; the wavefront that
+// finishes a bucket's LAST task then sums that bucket's partials (64 at a time through the same tree) into the bucket array.  With
 // uniform scalars there are no tasks and those workgroups return at once.
 // Hand-off of the partials between wavefronts: plain stores, s_waitcnt, agent-scope release, relaxed agent-scope counter; the last
 // arriver acquires at agent scope before it loads (MI355X_MICROARCH.md, inter-workgroup visibility).  Nothing ever waits for another
 // wavefront, so the order in which the hardware places the workgroups cannot deadlock it.
 template <class F>
 __device__ __forceinline__ void heavy_tasks(const PackedAffine<F> *__restrict__ pts, const SortBufs &B, Xyzz<F> *partial, Xyzz<F> *__restrict__ buckets,
-                                            uint32_t first, uint32_t stride) {
+                                            uint32_t first, uint32_t stride, Xyzz<F> *tree) {
     const uint32_t ntasks = min(B.heavy_ctr[0], B.heavy_cap), lane = threadIdx.x;
     for (uint32_t wt = first; wt < ntasks; wt += stride) {
         const uint2 task = B.heavy_tasks[wt];
         const uint4 hb = B.heavy_buckets[task.x];   // (bucket id, first task, tasks, -)
         const uint32_t len = B.counts[hb.x], lo = (task.y * 64 + lane) * HEAVY_SEG;
-        Xyzz<F> acc = sum_list(pts, B.sorted + B.bucket_off[hb.x] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u);
-#pragma unroll 1
-        for (int d = 32; d >= 1; d >>= 1) {
-            const Xyzz<F> o = shfl_down_xyzz(acc, d);
-            xyzz_add(acc, o);
-        }
+        wave_tree_sum(sum_list(pts, B.sorted + B.bucket_off[hb.x] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u), tree);
         uint32_t done = 0;
         if (lane == 0) {
-            partial[wt] = acc;
+            partial[wt] = tree[0];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the fence's own wait (MI355X_MICROARCH.md, compiler hazard)
@@ -661,17 +664,20 @@ __device__ __forceinline__ void heavy_tasks(const PackedAffine<F> *__restrict__ 
         if (done != hb.z) continue;                 // other tasks of this bucket are still running: their last one combines
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        acc = Xyzz<F>::inf();
-        for (uint32_t k = lane; k < hb.z; k += 64) {
-            const Xyzz<F> v = partial[hb.y + k];
-            xyzz_add(acc, v);
+        // the bucket's partials, 64 at a time: chunk 0 is the running sum, every further chunk's tree sum is added to it by one team
+        for (uint32_t k0 = 0; k0 < hb.z; k0 += 64) {
+            Xyzz<F> v = Xyzz<F>::inf();
+            if (k0 + lane < hb.z) v = partial[hb.y + k0 + lane];
+            if (k0 == 0) {
+                wave_tree_sum(v, tree);
+                if (lane == 0) buckets[hb.x] = tree[0];
+            } else {
+                wave_tree_sum(v, tree);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < 4) team4_add(lane, buckets + hb.x, tree, QuadDpp{});   // buckets[hb.x] += this chunk's sum
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
-#pragma unroll 1
-        for (int d = 32; d >= 1; d >>= 1) {
-            const Xyzz<F> o = shfl_down_xyzz(acc, d);
-            xyzz_add(acc, o);
-        }
-        if (lane == 0) buckets[hb.x] = acc;
     }
 }
 
@@ -682,7 +688,8 @@ __global__ __launch_bounds__(64, (F::CANON_WORDS == 8 ? 4 : 2)) void msm_accumul
                                                              const uint32_t *__restrict__ perm, Xyzz<F> *__restrict__ buckets,
                                                              uint32_t nbuckets, uint32_t heavy_th, SortBufs B, Xyzz<F> *partial, uint32_t heavy_blocks) {
     if (blockIdx.x < heavy_blocks) {
-        heavy_tasks(pts, B, partial, buckets, blockIdx.x, heavy_blocks);
+        __shared__ Xyzz<F> tree[64];   // 9 / 18 KB: sixteen (G1) / eight (G2) workgroups per CU still fit the 160 KB
+        heavy_tasks(pts, B, partial, buckets, blockIdx.x, heavy_blocks, tree);
         return;
     }
     const uint32_t r = (blockIdx.x - heavy_blocks) * 64 + threadIdx.x;
@@ -999,7 +1006,10 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         SortBufs B = sort_bufs(L);
         B.heavy_th = std::max<uint32_t>(32, 8 * (uint32_t)(((size_t)FIX_W * n_pad) / FIX_NB));
         const PackedAffine<F> *table = fix_table.template as<PackedAffine<F>>();
-        constexpr int FIX_PPT = 8;
+#ifndef ZK_FIX_PPT
+#define ZK_FIX_PPT 8
+#endif
+        constexpr int FIX_PPT = ZK_FIX_PPT;
         const uint32_t fix_total = (uint32_t)FIX_W * n_pad;
         hipLaunchKernelGGL((msm_fixed_partition_kernel<FIX_PPT, FIX_C>), dim3((fix_total + PREP_NT * FIX_PPT - 1) / (PREP_NT * FIX_PPT)), dim3(PREP_NT), 0, ls,
                            L.digits32.template as<int32_t>(), B, n_pad, fix_n, (uint32_t)first, fix_total, fixed_alias_mask());
