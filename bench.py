@@ -858,13 +858,6 @@ def main():
 
     # ---- secondary: Groth16 prove() wall-clock on a synthetic 2^20-constraint R1CS (BASELINE.json configs[3])
     if args.groth16_log_m and world == 1:
-        if os.environ.get("ZK_BENCH_EXPERIMENT") == "close_plan":   # experiment (profiles/r05_experiments.md): nothing of the headline left alive
-            plan.close()
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            _lib.check(lib.zk_cache_clear())
-            plan = None
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_groth16
@@ -903,8 +896,6 @@ def main():
     # ---- CPU baseline: reference-shaped pure-Python path on a bounded sample, on rank 0's host cores (for N > 1 the sample and the
     # C line are rank 0's chunk of the workload; the other ranks wait at the closing barrier)
     cpu = None
-    if plan is None:
-        plan = MsmPlan(_lib.GROUP_G1, n)
     if args.cpu_sample and rank == 0:
         cpu = cpu_baseline_msm(args, plan, scalars, points, d_scalars, d_points, n, stream, None if dist_on else result)
     if rank == 0:
