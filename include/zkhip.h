@@ -234,6 +234,10 @@ int zk_fr_spmv_dev(const void *d_row_ptr, const void *d_col, const void *d_vals,
  * zh_inv: `period` (1, 2, 4 or 8) HOST elements, 1 / Z_H repeats with that period on the coset. */
 int zk_plonk_quotient_dev(void *d_out, const void *const *d_in, const uint64_t *zh_inv, unsigned period, const uint64_t alpha[4],
                           const uint64_t beta[4], const uint64_t gamma[4], size_t n, void *stream);
+/* The per-row factors of PLONK's grand product (zkp/plonk/permutation.py:89-137 forms them in its accumulator loop), fused:
+ *   num[i] = (a + beta x + gamma)(b + 2 beta x + gamma)(c + 3 beta x + gamma),  den[i] = (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma)
+ * d_in: HOST-side array of the 7 device vectors a b c | s1 s2 s3 | x (x[i] = omega^i, the identity labels); canonical elements in and out. */
+int zk_plonk_perm_factors_dev(void *d_num, void *d_den, const void *const *d_in, const uint64_t beta[4], const uint64_t gamma[4], size_t n, void *stream);
 typedef struct zk_frvec zk_frvec;
 int zk_frvec_create(zk_frvec **ws);
 int zk_frvec_destroy(zk_frvec *ws);

@@ -786,6 +786,16 @@ int zk_plonk_quotient_dev(void *d_out, const void *const *d_in, const uint64_t *
         return ZK_OK;
     });
 }
+int zk_plonk_perm_factors_dev(void *d_num, void *d_den, const void *const *d_in, const uint64_t beta[4], const uint64_t gamma[4], size_t n, void *stream) {
+    return guarded([&] {
+        if (!d_in || !beta || !gamma || (n && (!d_num || !d_den))) return invalid("zk_plonk_perm_factors_dev: null pointer");
+        if (!scalars_canonical(beta, 1) || !scalars_canonical(gamma, 1)) return invalid("zk_plonk_perm_factors_dev: scalar not canonical (>= r)");
+        for (int k = 0; k < 7; k++)
+            if (n && !d_in[k]) return invalid("zk_plonk_perm_factors_dev: null input vector");
+        plonk_perm_factors(d_num, d_den, d_in, beta, gamma, n, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_frvec_create(zk_frvec **ws) {
     return guarded([&] {
         if (!ws) return invalid("zk_frvec_create: null pointer");

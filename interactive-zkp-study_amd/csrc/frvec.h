@@ -18,6 +18,9 @@ void fr_mul(void *d_out, const void *d_a, const void *d_b, size_t n, hipStream_t
 void plonk_quotient(void *d_out, const void *const *d_in, const uint64_t *zh_inv, unsigned period, const uint64_t alpha[4], const uint64_t beta[4],
                     const uint64_t gamma[4], size_t n, hipStream_t st);
 
+// The per-row factors of PLONK's grand product, fused; d_in: 7 device vectors a b c | s1 s2 s3 | x (x[i] = omega^i).
+void plonk_perm_factors(void *d_num, void *d_den, const void *const *d_in, const uint64_t beta[4], const uint64_t gamma[4], size_t n, hipStream_t st);
+
 // Scratch owned by whoever issues the calls (one per thread of use): power tables and the scan's per-level chunk totals.
 // One scratch object serves one stream at a time: its tables and scan levels are rewritten by every call and only stream
 // order keeps an earlier call's kernels ahead of the next call's writes.

@@ -121,6 +121,30 @@ __global__ __launch_bounds__(256) void plonk_quotient_kernel(uint32_t *__restric
     stc(out + i * 8, fe_mul(tot, A.zh_inv_r2[i % A.period]));        // (S / R) * zh_inv R^2 / R
 }
 
+// ------------------------------------------------------------------------------ PLONK grand product, the per-row factors fused
+// num[i] = (a + beta x + gamma)(b + beta K1 x + gamma)(c + beta K2 x + gamma),   den[i] = (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma)
+// with x = omega^i, K1 = 2, K2 = 3 (zkp/plonk/permutation.py:89-137 forms them row by row on Python integers; the device prover
+// then takes prefix / suffix products of them).  One pass over the seven input vectors instead of six linear combinations and four
+// products (ten launches, each streaming two or three vectors of n elements).  Plain values in and out: the first two factors
+// of each product are brought to Montgomery form, so that the product of the three carries no power of R.
+struct PermFactorArgs {
+    const uint32_t *in[7];   // a b c | s1 s2 s3 | x
+    Fr beta_m, gamma;
+};
+__global__ __launch_bounds__(256) void plonk_perm_factors_kernel(uint32_t *__restrict__ num, uint32_t *__restrict__ den, PermFactorArgs A, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    auto ld = [&](int k) { return ldc(A.in[k] + i * 8); };
+    auto add2 = [](const Fr &p, const Fr &q) { Fr r = fe_add(p, q); fe_wreduce<4>(r); return r; };   // < 2r
+    auto term = [&](const Fr &w, const Fr &bs) { return add2(add2(w, bs), A.gamma); };
+    auto prod3 = [](const Fr &t1, const Fr &t2, const Fr &t3) { return fe_mul(fe_mul(fe_to_mont(t1), fe_to_mont(t2)), t3); };   // (t1 R)(t2 R)/R * t3 / R
+    const Fr a = ld(0), b = ld(1), c = ld(2);
+    const Fr bx = fe_mul(ld(6), A.beta_m);                           // beta x, plain, < 2r
+    const Fr bx2 = add2(bx, bx), bx3 = add2(bx2, bx);
+    stc(num + i * 8, prod3(term(a, bx), term(b, bx2), term(c, bx3)));
+    stc(den + i * 8, prod3(term(a, fe_mul(ld(3), A.beta_m)), term(b, fe_mul(ld(4), A.beta_m)), term(c, fe_mul(ld(5), A.beta_m))));
+}
+
 // ------------------------------------------------------------------------------ scans
 // Values are kept in the form in which `op` is one field operation: plain for +, Montgomery for * (mont_mul of two
 // Montgomery values is the Montgomery product).  Bounds: op results < 2r for both.
@@ -346,6 +370,19 @@ void plonk_quotient(void *d_out, const void *const *d_in, const uint64_t *zh_inv
     for (unsigned k = 0; k < period; k++) A.zh_inv_r2[k] = fe_to_mont(dev_mont(host_fr(zh_inv + 4 * k)));
     A.period = period;
     hipLaunchKernelGGL(plonk_quotient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_out), A, n);
+    ZK_HIP(hipGetLastError());
+}
+
+void plonk_perm_factors(void *d_num, void *d_den, const void *const *d_in, const uint64_t beta[4], const uint64_t gamma[4], size_t n, hipStream_t st) {
+    if (n == 0) return;
+    PermFactorArgs A;
+    memset(&A, 0, sizeof(A));
+    for (int k = 0; k < 7; k++) A.in[k] = static_cast<const uint32_t *>(d_in[k]);
+    A.beta_m = fe_to_mont(host_fr(beta)).to_dev();
+    uint32_t w[8];
+    memcpy(w, gamma, 32);
+    A.gamma = fe_from_words<FrTag>(w);
+    hipLaunchKernelGGL(plonk_perm_factors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t *>(d_num), static_cast<uint32_t *>(d_den), A, n);
     ZK_HIP(hipGetLastError());
 }
 

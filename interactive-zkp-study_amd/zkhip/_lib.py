@@ -70,6 +70,7 @@ _PROTOS = {
     "zk_fr_quotient_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "zk_fr_spmv_dev": (ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _SZ, _VP]),
     "zk_plonk_quotient_dev": (ctypes.c_int, [_VP, ctypes.POINTER(_VP), _VP, ctypes.c_uint, _VP, _VP, _VP, _SZ, _VP]),
+    "zk_plonk_perm_factors_dev": (ctypes.c_int, [_VP, _VP, ctypes.POINTER(_VP), _VP, _VP, _SZ, _VP]),
     "zk_frvec_create": (ctypes.c_int, [ctypes.POINTER(_VP)]),
     "zk_frvec_destroy": (ctypes.c_int, [_VP]),
     "zk_fr_lincomb_dev": (ctypes.c_int, [_VP, ctypes.POINTER(_VP), _VP, ctypes.c_uint, _VP, _SZ, _VP]),

@@ -211,6 +211,14 @@ class FrVec:
         _lib.check(_lib.load().zk_fr_scan_dev(self._h, d_data, n, 1 if product else 0, 1 if reverse else 0, stream))
 
 
+def plonk_perm_factors(d_num, d_den, d_ins, beta, gamma, n, stream=0):
+    """The per-row numerators / denominators of PLONK's grand product in one pass (zk_plonk_perm_factors_dev); d_ins: the 7 device
+    vectors a b c | s1 s2 s3 | x (x[i] = omega^i)."""
+    ptrs = (ctypes.c_void_p * 7)(*[ctypes.c_void_p(int(p)) for p in d_ins])
+    sc = _lib.ints_to_limbs([int(beta), int(gamma)])
+    _lib.check(_lib.load().zk_plonk_perm_factors_dev(d_num, d_den, ptrs, _lib.ptr(sc[0:1]), _lib.ptr(sc[1:2]), n, stream))
+
+
 def plonk_quotient(d_out, d_ins, zh_inv, alpha, beta, gamma, n, stream=0):
     """Fused PLONK round-3 quotient on the evaluation coset (zk_plonk_quotient_dev); d_ins: the 15 device vectors
     a b c z zw | q_L q_R q_O q_M q_C | s1 s2 s3 | x L1, zh_inv: the `period` values of 1 / Z_H."""

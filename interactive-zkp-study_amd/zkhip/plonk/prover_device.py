@@ -15,12 +15,13 @@ selector / permutation polynomials and the SRS are device buffers and the rounds
 The host only hashes the transcript and handles the ~20 scalars between rounds.  With the same blinding scalars the
 proof equals the list prover's bit for bit (tests/test_gpu_plonk_device.py); the reference's quirks (PI(x) = 0, no
 blinding of t) are kept."""
+import os
 import secrets
 
 import numpy as np
 
 from .. import _lib
-from ..device import FrVec, MsmPlan, NttPlan, plonk_quotient
+from ..device import FrVec, MsmPlan, NttPlan, plonk_perm_factors, plonk_quotient
 from ..field import FR, CURVE_ORDER as R, get_root_of_unity, limbs_to_g1
 from .permutation import K1, K2
 from .prover import COSET_K, Proof, linearisation_scalars
@@ -211,7 +212,20 @@ class DevicePlonk:
         return z_ev
 
     def _accumulator_factors(self, cols, be, ga):
-        """Per row: num_i = prod_w (w_i + beta * k_w * omega^i + gamma), den_i = prod_w (w_i + beta * sigma_w(i) + gamma)."""
+        """Per row: num_i = prod_w (w_i + beta * k_w * omega^i + gamma), den_i = prod_w (w_i + beta * sigma_w(i) + gamma) -- one fused
+        pass over the seven vectors (zk_plonk_perm_factors_dev; ten lincomb / product launches until round 5)."""
+        n, B = self.n, self.buf
+        num, den = B["num"][:n], B["den"][:n]
+        sig = [self.evals["s_sigma%d" % k] for k in (1, 2, 3)]
+        if os.environ.get("ZK_PLONK_UNFUSED_FACTORS"):                          # A/B runs and the test that compares the two forms
+            return self._accumulator_factors_unfused(cols, be, ga)
+        plonk_perm_factors(num.data_ptr(), den.data_ptr(), [t.data_ptr() for t in (cols[0], cols[1], cols[2], sig[0], sig[1], sig[2], self.ident)],
+                           be, ga, n, self.st)
+        return num, den
+
+    def _accumulator_factors_unfused(self, cols, be, ga):
+        """The same factors by linear combinations and products of whole vectors (the form used until round 5; kept as the
+        cross-check of the fused kernel: tests/test_gpu_plonk_device.py)."""
         n, B = self.n, self.buf
         num, den, tmp = B["num"][:n], B["den"][:n], B["tmp"][:n]
         sig = [self.evals["s_sigma%d" % k] for k in (1, 2, 3)]

@@ -140,6 +140,36 @@ def test_device_prover_2pow12_verifies_and_rejects_tampering():
         dev.prove(_limbs(a), _limbs(b), _limbs(c_bad))
 
 
+def test_fused_permutation_factors_equal_the_vector_form_and_the_oracle():
+    """zk_plonk_perm_factors_dev (one pass over a b c | s1 s2 s3 | x) against the ten lincomb / product launches it replaced and
+    against Python integers (permutation.py:118-131), n = 64 and an odd length, beta / gamma near the field's edges."""
+    import torch
+    from zkhip.device import plonk_perm_factors
+    circuit, a, b, c = _chain_circuit(64, 11)
+    srs = SRS.generate(64 + 8, seed=42)
+    pp = preprocess(circuit, srs)
+    n = pp.n
+    dev = _device_from_circuit(circuit, pp, srs)
+    cols = [torch.from_numpy(_limbs(col).view(np.int64)).cuda() for col in (a, b, c)]
+    s1, s2, s3 = build_permutation_polynomials(pp.sigma, n, pp.domain)
+    for be, ga in ((0x1234567, 0x89ABCDEF), (R - 1, R - 2), (0, 5), (7, 0)):
+        num, den = dev._accumulator_factors(cols, be, ga)
+        got = [_lib.limbs_to_ints(t.cpu().numpy().view(np.uint64)) for t in (num, den)]
+        un, ud = dev._accumulator_factors_unfused(cols, be, ga)
+        assert got == [_lib.limbs_to_ints(t.cpu().numpy().view(np.uint64)) for t in (un, ud)]
+        dom = [int(d) for d in pp.domain]
+        want_n = [(int(a[i]) + be * dom[i] + ga) * (int(b[i]) + be * 2 * dom[i] + ga) * (int(c[i]) + be * 3 * dom[i] + ga) % R for i in range(n)]
+        want_d = [(int(a[i]) + be * int(s1[i]) + ga) * (int(b[i]) + be * int(s2[i]) + ga) * (int(c[i]) + be * int(s3[i]) + ga) % R for i in range(n)]
+        assert got == [want_n, want_d]
+    # a length that is not a multiple of the workgroup size
+    m = 37
+    outs = [torch.zeros((m, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+    ins = [t[:m].contiguous() for t in (cols[0], cols[1], cols[2], dev.evals["s_sigma1"], dev.evals["s_sigma2"], dev.evals["s_sigma3"], dev.ident)]
+    plonk_perm_factors(outs[0].data_ptr(), outs[1].data_ptr(), [t.data_ptr() for t in ins], 99, 1234, m, torch.cuda.current_stream().cuda_stream)
+    dom = [int(d) for d in pp.domain]
+    assert _lib.limbs_to_ints(outs[0].cpu().numpy().view(np.uint64)) == [(int(a[i]) + 99 * dom[i] + 1234) * (int(b[i]) + 198 * dom[i] + 1234) * (int(c[i]) + 297 * dom[i] + 1234) % R for i in range(m)]
+
+
 @pytest.mark.parametrize("zero_row", [0, 5, 15])
 def test_device_grand_product_with_a_zero_denominator_equals_the_reference_loop(zero_row):
     """permutation.py:118-135 divides row by row and py_ecc's x / 0 is 0: a zero denominator zeroes z from the NEXT row on and keeps
