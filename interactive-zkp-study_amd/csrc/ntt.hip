@@ -85,9 +85,17 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
 // rate; two stages on 4 elements need 144 registers and a 2^10-element tile: three wavefronts per SIMD, 79 % of the issue
 // rate (profiles/r02_pmc_sq_summary.csv), and although LDS is crossed four times per 8-bit digit instead of three a 2^22-point
 // transform takes 0.51 ms instead of 0.545 (both libraries on one box, a hundred round trips; 2^20: 0.147 instead of 0.155).
-template <int R, bool LAST>
+// GTW (the T1K kernels): the LDS table holds the twiddles of stages 0..5 only (63 entries, 2.3 KB instead of 9: with the 36 KB tile
+// that is 38.25 KB per workgroup, FOUR workgroups per CU instead of three -- the T1K kernels need 127 registers, so the fourth
+// wavefront per SIMD fits); stages 6 and 7 (the first round of a pass over a 7- or 8-bit digit) read theirs from the global table,
+// consecutive lanes consecutive entries (L1 / L2 hits: the table has 128 entries).
+#ifndef ZK_NTT_TW_LDS_STAGES
+#define ZK_NTT_TW_LDS_STAGES 6   // 8: every stage's twiddles in LDS (9 KB table, three workgroups per CU: the round-5 A/B)
+#endif
+constexpr int NTT_TW_LDS_STAGES = ZK_NTT_TW_LDS_STAGES;
+template <int R, bool LAST, bool GTW>
 __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, uint32_t tile, uint32_t ntw, uint32_t lp, uint32_t g,
-                                          int s_hi) {
+                                          int s_hi, const Fr *__restrict__ gtw, uint32_t tw_shift) {
     const int s_lo = LAST ? 0 : s_hi - R + 1;
     const uint32_t ngroups = tile >> R;
     uint32_t kx[1 << R];   // swizzle of the element bits k << (s_lo + g): uniform over the wavefront
@@ -108,7 +116,11 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
             for (int q = 0; q < (1 << b); q++) {
                 const bool unit = LAST && q == 0;
                 Fr w;
-                if (!unit) w = lds_ld(tw, ntw, (1u << s) + (low | ((uint32_t)q << s_lo)));   // stage s: w^(j << (lp - 1 - s)) at 2^s + j
+                if (!unit) {
+                    const uint32_t j = low | ((uint32_t)q << s_lo);
+                    if (GTW && s >= NTT_TW_LDS_STAGES) w = gtw[(size_t)(j << (lp - 1 - s)) << tw_shift];
+                    else w = lds_ld(tw, ntw, (1u << s) + j);   // stage s: w^(j << (lp - 1 - s)) at 2^s + j
+                }
 #pragma unroll
                 for (int hi = 0; hi < (1 << (R - 1 - b)); hi++) {
                     const int k0 = (hi << (b + 1)) | q, k1 = k0 | (1 << b);
@@ -158,7 +170,7 @@ __device__ __forceinline__ Fr io_coset(const NttIoArgs &io, uint32_t i) {
 //              digit: 2^(g - gb) adjacent ELEMENTS and 2^gb adjacent TRANSFORMS of the batch (gb > 0 only with a transposed
 //              buffer, whose memory runs along the batch index), so that both sides of a transposing pass move >= 128-byte runs.
 //   T1K      : the tile holds 2^10 elements (the usual case): the limb planes of the tile then lie 4096 bytes apart and those of the
-//              twiddle table 1024 (the table is given 256 columns whatever the digit) -- constants the compiler folds into the
+//              twiddle table 256 (the table is given 64 columns whatever the digit) -- constants the compiler folds into the
 //              LDS instructions' offsets, pairing the limb accesses of an element into ds_read2st64_b32 / ds_write2st64_b32
 //              (five LDS instructions per element instead of nine)
 template <bool FINAL, bool IN_CANON, int IN_L, int OUT_L, bool T1K = false>
@@ -172,14 +184,14 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
     const uint32_t gb = HAS_GB ? P.gb : 0u, ga = g - gb, Gb1 = (1u << gb) - 1u, Ga1 = (1u << ga) - 1u;
     const uint32_t tile = T1K ? 1024u : 1u << (lp + g);
     const uint32_t ntw = 1u << lp;                     // entries of the twiddle table,
-    const uint32_t tws = T1K ? 256u : ntw;             // and the distance of its limb planes
+    const uint32_t tws = T1K ? (1u << NTT_TW_LDS_STAGES) : ntw;   // and the distance of its limb planes (T1K: stages 0..5 only, see ntt_round)
     uint32_t *data = lds;
     uint32_t *tw = lds + NL * tile;
     // blockIdx.y = index of the transform (of the group of 2^gb transforms) inside a batch of independent transforms
     const uint32_t bbase = blockIdx.y << gb;
     const uint32_t *in_c = static_cast<const uint32_t *>(in_v);   // canonical input or the 8-word scratch: both 32 bytes per element
 
-    for (uint32_t i = t + 1; i < ntw; i += NTT_NT) {
+    for (uint32_t i = t + 1; i < (T1K ? min(ntw, 1u << NTT_TW_LDS_STAGES) : ntw); i += NTT_NT) {
         const uint32_t st = 31u - (uint32_t)__clz((int)i), j = i - (1u << st);
         lds_st(tw, tws, i, tile_tw[(size_t)(j << (lp - 1 - st)) << P.tw_shift]);
     }
@@ -245,10 +257,10 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
         const int R = sh == 0 ? 1 : 2;
         const bool last = (sh - R + 1 == 0);
         if (R == 2) {
-            if (last) ntt_round<2, true>(data, tw, tile, tws, lp, g, sh);
-            else ntt_round<2, false>(data, tw, tile, tws, lp, g, sh);
+            if (last) ntt_round<2, true, T1K>(data, tw, tile, tws, lp, g, sh, tile_tw, P.tw_shift);
+            else ntt_round<2, false, T1K>(data, tw, tile, tws, lp, g, sh, tile_tw, P.tw_shift);
         } else {
-            ntt_round<1, true>(data, tw, tile, tws, lp, g, sh);  // a single stage is only ever the last one
+            ntt_round<1, true, T1K>(data, tw, tile, tws, lp, g, sh, tile_tw, P.tw_shift);  // a single stage is only ever the last one
         }
         sh -= R;
         __syncthreads();
@@ -612,7 +624,7 @@ void NttPlan::launch_passes(const void *d_in, void *d_out, bool inverse, unsigne
         const uint32_t tile = 1u << (lp + P.g);
         static const bool no_1k = getenv("ZK_NTT_NO_T1K") != nullptr;    // A/B runs of the round-5 experiment (tools/ab_ntt.py)
         const bool t1k = !no_1k && tile == 1024 && il == NTT_PLAIN && ol == NTT_PLAIN && lp <= 8 && !(final_pass && first_pass);
-        const size_t lds = ((size_t)NL * tile + (size_t)NL * (t1k ? 256u : (1u << lp))) * sizeof(uint32_t);
+        const size_t lds = ((size_t)NL * tile + (size_t)NL * (t1k ? (1u << NTT_TW_LDS_STAGES) : (1u << lp))) * sizeof(uint32_t);
         const unsigned blocks = (unsigned)(n >> (lp + P.g - P.gb));
         const dim3 grid(blocks, batch >> P.gb);
         const Fr *A = twA_[dir].as<Fr>(), *B = twB_[dir].as<Fr>();
