@@ -113,7 +113,7 @@ def run(log_n, reps, profile=False, pause_after_proofs=0.0, warm=3):
         pr = cProfile.Profile()
         torch.cuda.synchronize()
         pr.enable()
-        dev.prove(*cols)
+        proof = dev.prove(*cols)            # (the checks below read the LAST proof's polynomials off the device: keep them a pair)
         torch.cuda.synchronize()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
