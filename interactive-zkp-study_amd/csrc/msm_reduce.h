@@ -13,14 +13,14 @@
 // consecutive lanes on consecutive buckets (coalesced loads, unlike the bottom-up order of rounds 1-4, in which a lane owned 2^m
 // CONSECUTIVE buckets), (s+1) * half additions per step, 2 nb in total, depth log2 nb.
 //
-// Round 5: what bounds this stage is the LATENCY of the additions on the upper levels, where there are fewer additions than lanes
-// (19 + 10 dependent additions of 8.7 us (G1) / 24 us (G2) each: profiles/r04_experiments.md section 8).  Two changes:
-//   * every level that needs a barrier runs its additions on TEAMS of lanes (curve.h team4_add / team2_add: the products of one
-//     addition side by side in four lanes, ~1300 instructions deep instead of ~3500, or in two, ~1800): four lanes while a
-//     quarter of the workgroup's lanes covers the level, two lanes below that -- two lanes cost the same lane-instructions per
-//     addition as one and split a level into rounds that load every wavefront alike;
-//   * the lower levels run at two wavefronts per SIMD with four buckets per thread instead of one wavefront with eight, one lane
-//     per addition and no barrier while a thread's additions depend only on its own earlier ones (half >= NT).
+// Round 5.  A general addition is ~3400 instructions in one lane (G1; 10 100 in G2) and a lone wavefront issues them at 83 % of the
+// SIMD's rate (tools/reduce_probe.hip ilp): a level of the tree with fewer additions than lanes costs one whole addition, 6-7 us,
+// whatever the occupancy -- 19 + 10 of them in rounds 1-4.  The only way to shorten such a level is more lanes per addition:
+//   * a step's whole rounds of NT additions take one lane each (the cheapest form while every SIMD is loaded: the lower levels,
+//     at two wavefronts per SIMD, the first two steps without barriers: half >= NT);
+//   * what is left of a step -- and every step above -- goes to TEAMS (curve.h team2_add / team4_add: the products of one addition
+//     side by side in two lanes, ~2100 instructions deep, or in four, ~1300), two lanes while more than NT/4 additions remain,
+//     four below that.
 // msm_reduce_block_kernel:   one workgroup per block of 2^BL buckets (BL = 11): steps 0 .. BL-1 inside the block.
 // msm_reduce_window_kernel:  one workgroup per window (or per aligned group of blocks): the steps over the block index -- the fold
 //                            of region 0 carries every block's T and its BL partial O_l along (BL + 1 + s) * half additions at step s.
