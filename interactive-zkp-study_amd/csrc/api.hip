@@ -27,23 +27,30 @@ int require_device() {
     return ZK_OK;
 }
 
-// msm.h: the process-wide pool of lane streams, four per device, created together on first use (under a lock: plans may be
-// created from several threads) and left to the runtime at process exit.
-hipStream_t lane_stream(int device, int group, int lane) {
+// msm.h: the process-wide pool of lane streams, three per device, created together on first use (under a lock: plans may be
+// created and used from several threads) and left to the runtime at process exit; handed out in turn.
+hipStream_t lane_stream_next(int device) {
+    struct Pool {
+        std::array<hipStream_t, 3> st{};
+        unsigned next = 0;
+    };
     static std::mutex mu;
-    static std::map<int, std::array<hipStream_t, 4>> pools;
+    static std::map<int, Pool> pools;
     std::lock_guard<std::mutex> lock(mu);
     auto it = pools.find(device);
     if (it == pools.end()) {
         int cur = -1;
         ZK_HIP(hipGetDevice(&cur));
         if (cur != device) ZK_HIP(hipSetDevice(device));
-        std::array<hipStream_t, 4> p{};
-        for (auto &st : p) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        Pool p;
+        for (auto &st : p.st) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         if (cur != device) ZK_HIP(hipSetDevice(cur));
         it = pools.emplace(device, p).first;
     }
-    return it->second[(size_t)(lane + (group == ZK_GROUP_G2 ? 3 : 0)) & 3u];
+    Pool &p = it->second;
+    const hipStream_t st = p.st[p.next];
+    p.next = (p.next + 1) % 3;
+    return st;
 }
 
 // Plans own device memory, streams and (NTT) a per-device kernel attribute: they work on the device they were created on only.

@@ -25,15 +25,17 @@ struct MsmPlanBase {
     virtual int bind_points(const void *d_points, size_t n, hipStream_t st) = 0;
     virtual int submit_bound(const void *d_scalars, size_t first, size_t n, hipStream_t st) = 0;
 };
-// The streams the lanes of ALL plans run on: four per device, created together the first time a plan needs one and never destroyed.
-// Why a pool: the HIP runtime spreads streams over its (by default four) hardware queues in creation order, and which of a prover's
-// MSMs end up sharing a queue decides how their kernels interleave -- the same Groth16 proof took 9.07 / 9.15 / 9.29 / 9.44 ms with
-// 1 / 0 / 2 / 3 unrelated streams created before the prover's plans (profiles/r05_experiments.md: the "in-process penalty" of
-// bench.py, whose secondaries create and destroy plans before the prover).  With the pool the queue a lane runs on depends on the
-// lane's index and the plan's group only: G1 lanes take streams 0 1 2, G2 lanes 3 0 1 -- the three MSMs of a Groth16 proof (two G1
-// lanes, one G2 lane) always sit on three different streams, whatever else the process has created.  Plans that share a stream
-// serialise on it; they are not in flight together in either prover.
-hipStream_t lane_stream(int device, int group, int lane);
+// The streams MSMs run on: three per device for ALL plans, created together the first time one is needed and never destroyed;
+// every submission takes the next one in turn (whatever plan and lane it belongs to: a lane's workspace is free again only once
+// its previous submission has been collected, so it may change stream from one submission to the next).
+// Why: the HIP runtime spreads streams over its four hardware queues in creation order, and MSMs whose streams share a queue run
+// strictly one after the other -- the same Groth16 proof took 9.07 / 9.15 / 9.29 / 9.44 ms with 1 / 0 / 2 / 3 unrelated streams created
+// before the prover's plans (the "in-process penalty" of bench.py, whose secondaries create and destroy plans before the prover),
+// and with one stream per lane the kernel timelines show the second G1 MSM of a proof, or its G2 one, waiting behind another MSM
+// of the same proof on a shared queue (profiles/r05_experiments.md section 2).  Three streams plus the caller's own fill the four
+// queues one each, and the three MSMs a Groth16 proof submits back to back (or the three commitments of a PLONK round) always
+// get three different ones.
+hipStream_t lane_stream_next(int device);
 
 // all_lanes: allocate every lane's workspace now (a plan that will see a stream of MSMs) instead of on first use;
 // chunk_log: log2 of the chunk size for MSMs beyond it (0 = the default 2^22; zk_msm_plan_create_ex)

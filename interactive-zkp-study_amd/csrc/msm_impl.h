@@ -848,13 +848,12 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         // the memsets above were issued on the null stream, which the lane's non-blocking stream does not wait for: make sure they
         // have landed before the lane's first kernel can run (it bumps the error counter in the header zeroed here)
         ZK_HIP(hipStreamSynchronize(0));
-        L.stream = lane_stream(device, group, (int)(&L - lanes));
         for (hipEvent_t *e : {&L.ev_in, &L.ev_consumed, &L.done}) ZK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         L.ready = true;
     }
     ~MsmPlanImpl() override {
         for (auto &L : lanes) {
-            if (L.stream) (void)hipStreamSynchronize(L.stream);   // (the stream belongs to the process-wide pool: msm.h lane_stream)
+            if (L.stream) (void)hipStreamSynchronize(L.stream);   // (the stream belongs to the process-wide pool: msm.h lane_stream_next)
             for (hipEvent_t e : {L.ev_in, L.ev_consumed, L.done})
                 if (e) (void)hipEventDestroy(e);
             for (auto &e : L.ev)
@@ -985,6 +984,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const int ticket = pick_lane();
         Lane &L = lanes[ticket];
         prepare_lane(L);
+        L.stream = lane_stream_next(device);
         const uint32_t n_pad = (uint32_t)pad_n(n);
         if (L.digits32.bytes < (size_t)FIX_W * pad_n(cap_n) * sizeof(int32_t)) L.digits32.alloc((size_t)FIX_W * pad_n(cap_n) * sizeof(int32_t));
         L.busy = true;
@@ -1090,6 +1090,7 @@ template <class F> struct MsmPlanImpl : MsmPlanBase {
         const int ticket = pick_lane();
         Lane &L = lanes[ticket];
         prepare_lane(L);
+        L.stream = lane_stream_next(device);
         L.busy = true;
         L.empty = (n == 0);
         L.profiled = profile;
