@@ -646,12 +646,25 @@ template <class F> __device__ __forceinline__ void wave_tree_sum(const Xyzz<F> &
 template <class F>
 __device__ __forceinline__ void heavy_tasks(const PackedAffine<F> *__restrict__ pts, const SortBufs &B, Xyzz<F> *partial, Xyzz<F> *__restrict__ buckets,
                                             uint32_t first, uint32_t stride, Xyzz<F> *tree) {
-    const uint32_t ntasks = min(B.heavy_ctr[0], B.heavy_cap), lane = threadIdx.x;
-    for (uint32_t wt = first; wt < ntasks; wt += stride) {
-        const uint2 task = B.heavy_tasks[wt];
-        const uint4 hb = B.heavy_buckets[task.x];   // (bucket id, first task, tasks, -)
-        const uint32_t len = B.counts[hb.x], lo = (task.y * 64 + lane) * HEAVY_SEG;
-        wave_tree_sum(sum_list(pts, B.sorted + B.bucket_off[hb.x] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u), tree);
+    const uint32_t ntasks = __builtin_amdgcn_readfirstlane(min(B.heavy_ctr[0], B.heavy_cap));
+    for (uint32_t wt_i = first; wt_i < ntasks; wt_i += stride) {
+        // Nothing but the task number (a scalar register) lives across the list loop, which leaves no vector register free (four
+        // wavefronts x 128): the task's descriptors are read again behind it (the asm makes the number opaque, so the compiler
+        // cannot keep them) and the lane number is taken from mbcnt again.
+        uint32_t wt = __builtin_amdgcn_readfirstlane(wt_i);
+        {
+            const uint32_t lane = threadIdx.x;
+            const uint32_t tx = __builtin_amdgcn_readfirstlane(B.heavy_tasks[wt].x), ty = __builtin_amdgcn_readfirstlane(B.heavy_tasks[wt].y);
+            const uint32_t bucket = __builtin_amdgcn_readfirstlane(B.heavy_buckets[tx].x);
+            const uint32_t len = __builtin_amdgcn_readfirstlane(B.counts[bucket]), lo = (ty * 64 + lane) * HEAVY_SEG;
+            wave_tree_sum(sum_list(pts, B.sorted + B.bucket_off[bucket] + min(lo, len), lo < len ? min((uint32_t)HEAVY_SEG, len - lo) : 0u), tree);
+        }
+        asm volatile("" : "+s"(wt));
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // one wavefront per workgroup
+        uint2 task;
+        task.x = __builtin_amdgcn_readfirstlane(B.heavy_tasks[wt].x);
+        const uint4 hb_v = B.heavy_buckets[task.x];   // (bucket id, first task, tasks, -)
+        const uint4 hb = make_uint4(__builtin_amdgcn_readfirstlane(hb_v.x), __builtin_amdgcn_readfirstlane(hb_v.y), __builtin_amdgcn_readfirstlane(hb_v.z), 0u);
         uint32_t done = 0;
         if (lane == 0) {
             partial[wt] = tree[0];
