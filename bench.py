@@ -570,11 +570,14 @@ def main():
         ref = d.clone()
         nplan = NttPlan(L)
         # The chip clocks down while it idles and takes a few milliseconds of work to come back: five timed round trips straight
-        # after a synchronisation read 0.63 ms per 2^22-point transform, twenty after ten untimed ones 0.56, a hundred 0.51.
-        for _ in range(10):
+        # after a synchronisation read 0.63 ms per 2^22-point transform, twenty after ten untimed ones 0.56, a hundred 0.51 (round 2;
+        # round 5: 0.57 / 0.51 / 0.46-0.47, tools/ab_ntt.py).  Sixty untimed round trips (~60 ms of work) first, like the headline's
+        # priming steps, then forty timed: the sustained rate, which is what a prover's transforms run at behind its MSMs.
+        ntt_warm = 60
+        for _ in range(ntt_warm):
             nplan.run(d.data_ptr(), False, None, stream)
             nplan.run(d.data_ptr(), True, None, stream)
-        reps = 20
+        reps = 40
         fence()
         tn0 = time.perf_counter()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -593,7 +596,7 @@ def main():
             span, exact = float(tt[0].item()), float(tt[1].item()) == 0.0
         extra["ntt"] = {"log_n": L, "ms_per_transform": round(ms, 4), "elements_per_s": m / (ms * 1e-3),
                         "algorithmic_GBps": 64.0 * m / (ms * 1e-3) / 1e9, "hbm_frac": 64.0 * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "roundtrip_exact": exact, "timed_round_trips": reps, "warmup_round_trips": 10}
+                        "roundtrip_exact": exact, "timed_round_trips": reps, "warmup_round_trips": ntt_warm}
         # the same in the shape of the headline's roofline object (algorithmic bytes: 64 B per element and transform);
         # traffic: the committed counter passes' FETCH + WRITE over the three pass kernels (16-byte loads corrected x2 as calibrated:
         # profiles/r04_fetch_calibration.md), for this size only

@@ -89,6 +89,14 @@ __device__ __forceinline__ void st_canon(uint32_t *p, const Fr &v) {
 // that is 38.25 KB per workgroup, FOUR workgroups per CU instead of three -- the T1K kernels need 127 registers, so the fourth
 // wavefront per SIMD fits); stages 6 and 7 (the first round of a pass over a 7- or 8-bit digit) read theirs from the global table,
 // consecutive lanes consecutive entries (L1 / L2 hits: the table has 128 entries).
+// Wave priority (s_setprio).  1: a workgroup's first phase -- global loads, conversion, LDS stores up to the first barrier -- runs at
+// priority 3: the SIMD arbiter otherwise serves its oldest wavefronts first, a newly placed workgroup issues its loads only in the
+// gaps the older ones leave, and its memory latency starts late (tools/ntt_phase_probe.py: a quarter of a workgroup's life went
+// into that phase).  2^22: 0.469-0.475 -> 0.462-0.464 ms, 2^24: 2.00-2.02 -> 1.97, 2^20 unchanged (three alternating pairs).  2: the
+// epilogue too; 3 / 4: the LDS loads / stores of every round as well -- no further gain (profiles/r05_experiments.md section 4).
+#ifndef ZK_NTT_PRIO
+#define ZK_NTT_PRIO 1
+#endif
 #ifndef ZK_NTT_TW_LDS_STAGES
 #define ZK_NTT_TW_LDS_STAGES 6   // 8: every stage's twiddles in LDS (9 KB table, three workgroups per CU: the round-5 A/B)
 #endif
@@ -107,8 +115,14 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
         const uint32_t jb = ((rest >> s_lo) << (s_hi + 1)) | low;
         const uint32_t sb = swz((jb << g) | c);
         Fr x[1 << R];
+#if ZK_NTT_PRIO >= 3
+        __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) x[k] = lds_ld(data, tile, sb ^ kx[k]);
+#if ZK_NTT_PRIO >= 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int b = R - 1; b >= 0; b--) {
             const int s = s_lo + b;
@@ -136,8 +150,14 @@ __device__ __forceinline__ void ntt_round(uint32_t *data, const uint32_t *tw, ui
                 }
             }
         }
+#if ZK_NTT_PRIO >= 4
+        __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) lds_st(data, tile, sb ^ kx[k], x[k]);
+#if ZK_NTT_PRIO >= 4
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 
@@ -157,6 +177,34 @@ __device__ __forceinline__ Fr io_twiddle(const NttIoArgs &io, uint32_t b, uint32
 __device__ __forceinline__ Fr io_coset(const NttIoArgs &io, uint32_t i) {
     return fe_mul(io.cosA[i & ((1u << io.cos_lh) - 1u)], io.cosB[i >> io.cos_lh]);
 }
+
+// Measurement builds only (-DZK_NTT_STAMPS, tools/ntt_phase_probe.py): thread 0 of every workgroup of a batch's first transform writes
+// the wall clock (100 MHz) at its phase boundaries -- entry, loads issued and converted, first barrier, every round's barrier, stores
+// issued, stores done -- and its hardware id to zk_ntt_stamp_buf[pass][workgroup][16].  Compiled out of the library.
+#ifdef ZK_NTT_STAMPS
+__device__ unsigned long long *zk_ntt_stamp_buf = nullptr;
+#define NTT_STAMP(pass, k)                                                                                             \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && zk_ntt_stamp_buf != nullptr && blockIdx.x < 4096)                   \
+            zk_ntt_stamp_buf[(((size_t)(pass)) * 4096 + blockIdx.x) * 16 + (k)] = wall_clock64();                      \
+    } while (0)
+#define NTT_STAMP_HWID(pass)                                                                                           \
+    do {                                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && zk_ntt_stamp_buf != nullptr && blockIdx.x < 4096) {                 \
+            uint32_t hw, xcc;                                                                                          \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                           \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                         \
+            zk_ntt_stamp_buf[(((size_t)(pass)) * 4096 + blockIdx.x) * 16 + 15] = ((unsigned long long)xcc << 32) | hw; \
+        }                                                                                                              \
+    } while (0)
+extern "C" int zk_ntt_set_stamp_buffer(void *d_buf) {
+    unsigned long long *p = static_cast<unsigned long long *>(d_buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(zk_ntt_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#else
+#define NTT_STAMP(pass, k) do { } while (0)
+#define NTT_STAMP_HWID(pass) do { } while (0)
+#endif
 
 // One pass over one digit.  Element values stay < 2r in LDS and in the scratch buffer between
 // passes (9-limb form in LDS, 8 words = 32 B in the scratch); only the first load and the last store use the canonical
@@ -178,6 +226,13 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
                                                           const Fr *__restrict__ tile_tw, const Fr *__restrict__ twA,
                                                           const Fr *__restrict__ twB, Fr scale, NttPassParams P, NttIoArgs io) {
     extern __shared__ uint32_t lds[];
+    constexpr int STAMP_PASS = FINAL ? 2 : (IN_CANON ? 0 : 1);   // measurement builds: which row of the stamp buffer
+    (void)STAMP_PASS;
+    NTT_STAMP(STAMP_PASS, 0);
+    NTT_STAMP_HWID(STAMP_PASS);
+#if ZK_NTT_PRIO >= 1
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t t = threadIdx.x;
     const uint32_t lp = P.lp, g = P.g, G = 1u << g;
     constexpr bool HAS_GB = (IN_L == NTT_TRANSPOSED || OUT_L == NTT_TRANSPOSED);
@@ -249,7 +304,14 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             lds_st(data, tile, swz((j << g) | c), v);
         }
     }
+    NTT_STAMP(STAMP_PASS, 1);
+#if ZK_NTT_PRIO >= 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
+    NTT_STAMP(STAMP_PASS, 2);
+    int stamp_k = 3;
+    (void)stamp_k;
 
     // decimation-in-frequency butterflies over the digit index j (slot = j * G + c), two stages per LDS round trip (radix-4 in
     // registers: four elements per thread and round, see the plan's tile size)
@@ -264,8 +326,12 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
         }
         sh -= R;
         __syncthreads();
+        NTT_STAMP(STAMP_PASS, stamp_k++);
     }
 
+#if ZK_NTT_PRIO >= 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     if (!FINAL) {
         const uint32_t sh = P.L - lp - P.sp;
         for (uint32_t e = t; e < tile; e += NTT_NT) {   // in LDS order: the digit comes out bit-reversed, k = brev(position)
@@ -308,6 +374,11 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             st_canon_2r(out_c + io_addr<OUT_L>(P.L, io, b, oidx) * 8, x);
         }
     }
+#ifdef ZK_NTT_STAMPS
+    NTT_STAMP(STAMP_PASS, 12);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NTT_STAMP(STAMP_PASS, 13);
+#endif
 }
 
 // x[j] *= A[j & mask] * B[j >> lh]   (two-level table of powers g^j, Montgomery form); canonical in/out
