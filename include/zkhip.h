@@ -165,6 +165,15 @@ int zk_ntt_dev(zk_ntt_plan *plan, void *d_data, int inverse, const uint64_t cose
  * coefficient list shorter than the domain (zkp/plonk/polynomial.py:263-285, 292-341; the coset form zkp/plonk/utils.py:145-177)
  * without the zero fill and the copy into a domain-sized buffer. */
 int zk_ntt_dev_padded(zk_ntt_plan *plan, const void *d_in, void *d_out, size_t in_len, int inverse, const uint64_t coset_shift[4], void *stream);
+/* `jobs` (<= 4) independent transforms of the plan's size in ONE launch per pass: job b reads d_in[b] (its first min(in_len, n)
+ * elements; the rest counts as zero) and writes d_out[b]; d_out[b] == d_in[b] is allowed, any other overlap between the buffers is
+ * ZK_ERR_INVALID.  d_in / d_out are HOST arrays of DEVICE pointers.  Direction, in_len and coset shift are shared.  What a prover does
+ * with the three polynomials of a round -- zkp/groth16/poly_utils.py:116-125 (A, B, C to coefficients, then onto the coset),
+ * zkp/plonk/prover/round1.py (a, b, c) -- one fft()/ifft() call each (zkp/plonk/polynomial.py:316-378): transforms that share
+ * their launches share the chip, one job's load and store phases run under the others' butterflies (three 2^20-point transforms:
+ * 0.31 ms against 0.36 one after the other). */
+int zk_ntt_dev_multi(zk_ntt_plan *plan, unsigned jobs, const void *const *d_in, void *const *d_out, size_t in_len, int inverse,
+                     const uint64_t coset_shift[4], void *stream);
 /* `batch` independent transforms of the plan's size stored back to back in d_data (no coset shift). */
 int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream);
 /* Batched transform between two DEVICE buffers whose layouts are those of the four-step (multi-GPU) transform, so that the

@@ -691,6 +691,22 @@ int zk_ntt_dev_padded(zk_ntt_plan *plan, const void *d_in, void *d_out, size_t i
         return ZK_OK;
     });
 }
+int zk_ntt_dev_multi(zk_ntt_plan *plan, unsigned jobs, const void *const *d_in, void *const *d_out, size_t in_len, int inverse,
+                     const uint64_t coset_shift[4], void *stream) {
+    return guarded([&] {
+        if (!plan || (jobs && (!d_in || !d_out))) return invalid("zk_ntt_dev_multi: null pointer");
+        if (jobs > NTT_MULTI_MAX) return invalid("zk_ntt_dev_multi: at most 4 transforms per call");
+        for (unsigned b = 0; b < jobs; b++) {
+            if (!d_out[b] || (in_len && !d_in[b])) return invalid("zk_ntt_dev_multi: null buffer");
+            for (unsigned c = 0; c < b; c++)
+                if (d_out[b] == d_out[c] || d_out[b] == d_in[c] || d_in[b] == d_out[c]) return invalid("zk_ntt_dev_multi: a buffer is written by one transform and used by another");
+        }
+        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev_multi")) return rc;
+        if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_dev_multi: coset_shift must be a canonical non-zero element of F_r");
+        plan->impl->run_multi(d_in, d_out, jobs, in_len, inverse != 0, coset_shift, (hipStream_t)stream);
+        return ZK_OK;
+    });
+}
 int zk_ntt_dev_batch(zk_ntt_plan *plan, void *d_data, unsigned batch, int inverse, void *stream) {
     return guarded([&] {
         if (!plan || (batch && !d_data)) return invalid("zk_ntt_dev_batch: null pointer");

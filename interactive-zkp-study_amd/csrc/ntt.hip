@@ -265,7 +265,8 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
                 if (IN_L == NTT_PLAIN && i >= io.in_len) {
                     v = Fr::zero();                                                     // zero-padded input: not read
                 } else {
-                    v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
+                    if (IN_L == NTT_PLAIN && io.multi) v = ld_canon(static_cast<const uint32_t *>(io.in_multi[b]) + (size_t)i * 8);
+                    else v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
                     if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
                     if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
                 }
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
                 if (IN_L == NTT_PLAIN && i >= io.in_len) {
                     v = Fr::zero();                                                     // zero-padded input: not read
                 } else {
-                    v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
+                    if (IN_L == NTT_PLAIN && io.multi) v = ld_canon(static_cast<const uint32_t *>(io.in_multi[b]) + (size_t)i * 8);
+                    else v = ld_canon(in_c + io_addr<IN_L>(P.L, io, b, i) * 8);
                     if (IN_L == NTT_BLOCKED_TW) v = fe_mul(v, io_twiddle(io, b, i));
                     if (IN_L == NTT_PLAIN && io.cos_in) v = fe_mul(v, io_coset(io, i));   // canonical < r times < 2r  ->  < 2r
                 }
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(NTT_NT) void ntt_pass_kernel(const void *__restrict
             const uint32_t oidx = (k1_base + ca) + ((kmid + (k << lmid_tot)) << P.l1), b = bbase + cb;
             if (OUT_L == NTT_BLOCKED_TW) x = fe_mul(x, io_twiddle(io, b, oidx));   // 2 * 2 < 169  ->  < 2r
             if (OUT_L == NTT_PLAIN && io.cos_out) x = fe_mul(x, io_coset(io, oidx));
-            st_canon_2r(out_c + io_addr<OUT_L>(P.L, io, b, oidx) * 8, x);
+            if (OUT_L == NTT_PLAIN && io.multi) st_canon_2r(static_cast<uint32_t *>(io.out_multi[b]) + (size_t)oidx * 8, x);
+            else st_canon_2r(out_c + io_addr<OUT_L>(P.L, io, b, oidx) * 8, x);
         }
     }
 #ifdef ZK_NTT_STAMPS
@@ -584,6 +587,35 @@ void NttPlan::run_padded(const void *d_in, void *d_out, size_t in_len, bool inve
         io.cos_out = inverse ? 1u : 0u;
     }
     launch_passes(d_in, d_out, inverse, 1, NTT_PLAIN, NTT_PLAIN, io, st);
+    ZK_HIP(hipGetLastError());
+}
+
+void NttPlan::run_multi(const void *const *d_in, void *const *d_out, unsigned jobs, size_t in_len, bool inverse, const uint64_t coset_shift[4], hipStream_t st) {
+    if (jobs == 0) return;
+    if (jobs > NTT_MULTI_MAX) throw std::runtime_error("zk_ntt_dev_multi: at most 4 transforms per call");
+    if (jobs == 1 || L_ == 0) {   // nothing to share (L = 0: no pass at all)
+        for (unsigned b = 0; b < jobs; b++) run_padded(d_in[b], d_out[b], in_len, inverse, coset_shift, st);
+        return;
+    }
+    const size_t n = (size_t)1 << L_;
+    NttIoArgs io;
+    io.in_len = (uint32_t)std::min<size_t>(in_len, n);
+    io.multi = 1;
+    io.batch = jobs;
+    for (unsigned b = 0; b < jobs; b++) {
+        io.in_multi[b] = d_in[b];
+        io.out_multi[b] = d_out[b];
+    }
+    if (coset_shift) {
+        const int d = inverse ? 1 : 0;
+        coset_tables(coset_shift, inverse);
+        io.cosA = cosA_[d].as<Fr>();
+        io.cosB = cosB_[d].as<Fr>();
+        io.cos_lh = lh_;
+        io.cos_in = inverse ? 0u : 1u;
+        io.cos_out = inverse ? 1u : 0u;
+    }
+    launch_passes(d_in[0], d_out[0], inverse, jobs, NTT_PLAIN, NTT_PLAIN, io, st);
     ZK_HIP(hipGetLastError());
 }
 

@@ -64,6 +64,7 @@ _PROTOS = {
     "zk_ntt_plan_destroy": (ctypes.c_int, [_VP]),
     "zk_ntt_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_int, _VP, _VP]),
     "zk_ntt_dev_padded": (ctypes.c_int, [_VP, _VP, _VP, _SZ, ctypes.c_int, _VP, _VP]),
+    "zk_ntt_dev_multi": (ctypes.c_int, [_VP, ctypes.c_uint, _VP, _VP, _SZ, ctypes.c_int, _VP, _VP]),
     "zk_ntt_dev_batch": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_int, _VP]),
     "zk_ntt_dev_io": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64, _VP, ctypes.c_int, _VP]),
     "zk_ntt_twiddle_dev": (ctypes.c_int, [_VP, _VP, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, _VP]),

@@ -104,6 +104,9 @@ class MsmPlan:
         return out
 
 
+_NO_MULTI = bool(__import__("os").environ.get("ZK_NTT_NO_MULTI"))
+
+
 class NttPlan:
     """Twiddle tables + scratch for in-place device NTTs of size 2^log_n (zk_ntt_plan_*)."""
 
@@ -133,6 +136,20 @@ class NttPlan:
         first in_len elements of d_in are read (zk_ntt_dev_padded) -- no zero fill, no copy into a domain-sized buffer."""
         k = None if coset_shift is None else _lib.ints_to_limbs([int(coset_shift)])
         _lib.check(_lib.load().zk_ntt_dev_padded(self._h, d_in, d_out, int(in_len), 1 if inverse else 0, None if k is None else _lib.ptr(k), stream))
+
+    def run_multi(self, pairs, in_len=None, inverse=False, coset_shift=None, stream=0):
+        """Up to four independent transforms in one launch per pass (zk_ntt_dev_multi): pairs = [(d_in, d_out), ...] device pointers,
+        d_out == d_in allowed; in_len (default n): elements read from every input, the rest counts as zero."""
+        if _NO_MULTI:   # measurement hook (profiles/r05_experiments.md): the same transforms one after the other
+            for d_in, d_out in pairs:
+                self.run_padded(d_in, d_out, (1 << self.log_n) if in_len is None else in_len, inverse, coset_shift, stream)
+            return
+        k = len(pairs)
+        ins = (ctypes.c_void_p * k)(*[p[0] for p in pairs])
+        outs = (ctypes.c_void_p * k)(*[p[1] for p in pairs])
+        shift = None if coset_shift is None else _lib.ints_to_limbs([int(coset_shift)])
+        _lib.check(_lib.load().zk_ntt_dev_multi(self._h, k, ins, outs, (1 << self.log_n) if in_len is None else int(in_len), 1 if inverse else 0,
+                                                None if shift is None else _lib.ptr(shift), stream))
 
     def run_batch(self, d_data, batch, inverse=False, stream=0):
         """`batch` independent transforms stored back to back in d_data (zk_ntt_dev_batch)."""

@@ -264,18 +264,17 @@ class ScaleProver:
         if not self.bound:
             self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
         # u_A, u_B, u_C = coefficient forms (the reference's R.A etc.): 3 inverse NTTs, written where the MSMs read them (the
-        # transforms run from one buffer to another: zk_ntt_dev_padded -- no copies)
+        # transforms run from one buffer to another -- no copies -- and the three of a group share one launch per pass:
+        # zk_ntt_dev_multi; their workgroups share the chip, 0.31 ms instead of 0.36 per group at 2^20)
         if self.profile is not None:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev[0].record()
-        for src, dst in ((d_a, ua), (d_b, ub), (d_c, d_c)):
-            self.ntt.run_padded(src.data_ptr(), dst.data_ptr(), m, True, None, st)
+        self.ntt.run_multi([(src.data_ptr(), dst.data_ptr()) for src, dst in ((d_a, ua), (d_b, ub), (d_c, d_c))], m, True, None, st)
         self.ext_b2[:m].copy_(ub)
         # H = (A*B - C) / Z on the coset 5*H: 3 coset NTTs + pointwise quotient + 1 coset inverse NTT.  The transforms go
         # FIRST: an accumulate kernel fills every wavefront slot a CU frees, so NTT workgroups queued behind an MSM would
         # wait for its whole grid, the H query would start last and finish alone.
-        for src, dst in ((ua, ca), (ub, cb), (d_c, cc)):
-            self.ntt.run_padded(src.data_ptr(), dst.data_ptr(), m, False, COSET_SHIFT, st)
+        self.ntt.run_multi([(src.data_ptr(), dst.data_ptr()) for src, dst in ((ua, ca), (ub, cb), (d_c, cc))], m, False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
         if self.bound:

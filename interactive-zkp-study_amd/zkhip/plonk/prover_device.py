@@ -123,6 +123,20 @@ class DevicePlonk:
         self.ntt_n.run_padded(evals.data_ptr(), out.data_ptr(), self.n, True, None, self.st)   # evals -> out[:n], no copy
         return out
 
+    def _interpolate_many(self, evals, outs):
+        """_interpolate of up to four columns in one launch per pass (zk_ntt_dev_multi): the transforms share the chip."""
+        for out in outs:
+            out[self.n:].zero_()
+        self.ntt_n.run_multi([(e.data_ptr(), o.data_ptr()) for e, o in zip(evals, outs)], self.n, True, None, self.st)
+        return outs
+
+    def _coset_many(self, coefs, outs):
+        """_coset of up to four coefficient buffers of one length in one launch per pass."""
+        m = min(coefs[0].shape[0], self.size)
+        assert all(min(c.shape[0], self.size) == m for c in coefs)
+        self.ntt_big.run_multi([(c.data_ptr(), o.data_ptr()) for c, o in zip(coefs, outs)], m, False, COSET_K, self.st)
+        return outs
+
     def _coset(self, coef, out=None):
         """Coefficient buffer -> evaluations on the coset k*H' (size, 4), into `out` when given."""
         if out is None:
@@ -323,9 +337,10 @@ class DevicePlonk:
 
         # round 1 (round1.py:55-108)
         B = self.buf
-        wires = [self._blinded(self._interpolate(col, B["w%d" % i]), blind[2 * i:2 * i + 2]) for i, col in enumerate(cols)]
+        wires = self._interpolate_many(cols, [B["w%d" % i] for i in range(3)])       # the three columns in one launch per pass
+        wires = [self._blinded(w, blind[2 * i:2 * i + 2]) for i, w in enumerate(wires)]
         tickets = [self._submit(w, n + 2) for w in wires]
-        ea, eb, ec = (self._coset(w, buf) for w, buf in zip(wires, self.work[:3]))   # round 3's coset evaluations of the wires need no challenge: under the MSMs
+        ea, eb, ec = self._coset_many(wires, self.work[:3])   # round 3's coset evaluations of the wires need no challenge: under the MSMs
         for name, t in zip(("a_comm", "b_comm", "c_comm"), tickets):
             limbs, inf = self.msm.collect_limbs(t)
             comm = None if inf else limbs_to_g1(limbs)[0]

@@ -272,3 +272,80 @@ def test_fr_quotient_kernel():
     got = co.from_limbs(dO.cpu().numpy().view(np.uint64))
     a, b, c = co.from_limbs(A), co.from_limbs(B), co.from_limbs(C)
     assert got == [((x * y - z) * zinv) % o.R for x, y, z in zip(a, b, c)]
+
+
+def _oracle_coset(X, n, inverse, k):
+    """coset_fft / coset_ifft of the oracle (utils.py:145-205): scale by k^i before a forward transform, by k^-i after an inverse."""
+    w = o.get_root_of_unity(n)
+    if k is None:
+        return co.ntt_arr(X, w, inverse)
+    if not inverse:
+        vals = co.from_limbs(X)
+        return co.ntt_arr(co.to_limbs([v * pow(k, i, o.R) % o.R for i, v in enumerate(vals)]), w, False)
+    vals = co.from_limbs(co.ntt_arr(X, w, True))
+    kinv = pow(k, -1, o.R)
+    return co.to_limbs([v * pow(kinv, i, o.R) % o.R for i, v in enumerate(vals)])
+
+
+@pytest.mark.parametrize("L,jobs,inverse,k,short", [(0, 3, False, None, False), (1, 2, True, None, False), (5, 3, False, 5, False), (8, 4, True, 5, True),
+                                                    (9, 3, False, None, True), (12, 3, True, None, False), (13, 2, False, 7, True), (16, 4, False, None, False),
+                                                    (17, 3, True, 5, False)])
+def test_ntt_multi_vs_oracle(L, jobs, inverse, k, short):
+    """zk_ntt_dev_multi: up to four transforms of separate buffers in one launch per pass -- one, two and three passes, both
+    directions, with and without a coset shift, zero-padded inputs (in_len < n), job 0 in place and the others out of place --
+    every output against the oracle's transform of that job alone, and the inputs of the out-of-place jobs untouched."""
+    import torch
+    rng = np.random.default_rng(7700 + 31 * L + jobs)
+    n = 1 << L
+    in_len = max(1, (n * 3) // 4) if short else n
+    st = torch.cuda.current_stream().cuda_stream
+    plan = NttPlan(L)
+    Xs, want = [], []
+    for b in range(jobs):
+        X = rand_fr_limbs(rng, n) if L <= 12 else _fast_rand(rng, n)
+        Xs.append(X)
+        Z = X.copy()
+        Z[in_len:] = 0
+        want.append(_oracle_coset(Z, n, inverse, k))
+    d_in = [torch.from_numpy(X.view(np.int64).copy()).cuda() for X in Xs]
+    d_out = [d_in[0]] + [torch.full((n, 4), -1, dtype=torch.int64, device="cuda") for _ in range(jobs - 1)]
+    plan.run_multi([(a.data_ptr(), b.data_ptr()) for a, b in zip(d_in, d_out)], in_len, inverse, k, st)
+    torch.cuda.synchronize()
+    for b in range(jobs):
+        assert np.array_equal(d_out[b].cpu().numpy().view(np.uint64), want[b]), (L, b)
+        if b:
+            assert np.array_equal(d_in[b].cpu().numpy().view(np.uint64), Xs[b]), (L, b)
+    plan.close()
+
+
+def test_ntt_multi_at_2pow20_and_refusals():
+    """Three 2^20-point transforms in one launch per pass (what the Groth16 prover's groups are) against the oracle in full; a buffer
+    written by one job and used by another, more than four jobs and a null buffer are refused."""
+    import ctypes
+    import torch
+    L, n = 20, 1 << 20
+    st = torch.cuda.current_stream().cuda_stream
+    plan = NttPlan(L)
+    Xs = [_fast_rand(np.random.default_rng(7800 + b), n) for b in range(3)]
+    w = o.get_root_of_unity(n)
+    d_in = [torch.from_numpy(X.view(np.int64).copy()).cuda() for X in Xs]
+    d_out = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+    for inverse in (False, True):
+        plan.run_multi([(a.data_ptr(), b.data_ptr()) for a, b in zip(d_in, d_out)], n, inverse, None, st)
+        torch.cuda.synchronize()
+        for b in range(3):
+            assert np.array_equal(d_out[b].cpu().numpy().view(np.uint64), co.ntt_arr(Xs[b], w, inverse)), (inverse, b)
+    lib = _lib.load()
+
+    def call(pairs):
+        ins = (ctypes.c_void_p * len(pairs))(*[p[0] for p in pairs])
+        outs = (ctypes.c_void_p * len(pairs))(*[p[1] for p in pairs])
+        return lib.zk_ntt_dev_multi(plan._h, len(pairs), ins, outs, n, 0, None, st)
+    a, b, c = (t.data_ptr() for t in d_out)
+    assert call([(a, b), (b, c)]) != 0             # b written by job 0, read by job 1
+    assert call([(a, c), (b, c)]) != 0             # c written twice
+    assert call([(a, a)] * 5) != 0                 # more than four
+    assert call([(a, a), (b, None)]) != 0          # null output
+    assert call([(a, a), (b, b)]) == 0             # in place is fine
+    torch.cuda.synchronize()
+    plan.close()
