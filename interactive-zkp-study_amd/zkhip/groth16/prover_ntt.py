@@ -405,8 +405,7 @@ class ShardedScaleProver(ScaleProver):
         self.ext_a[m:] = _dev(_lib.ints_to_limbs([1, r, 0]))
         self.ext_b1[m:] = _dev(_lib.ints_to_limbs([0, 0, 1]))
         self.ext_b2[m:] = _dev(_lib.ints_to_limbs([1, s]))
-        for d in (ua, ub, d_c):
-            self.ntt.run(d.data_ptr(), True, None, st)
+        self.ntt.run_multi([(d.data_ptr(), d.data_ptr()) for d in (ua, ub, d_c)], m, True, None, st)   # one launch per pass for the three
         self.ext_b2[:m].copy_(ub)
 
         def submit(plan, scal, pts, total, point_bytes):
@@ -416,8 +415,7 @@ class ShardedScaleProver(ScaleProver):
         ca.copy_(ua)                                                                  # transforms first, the G2 MSM leads: see ScaleProver.prove
         cb.copy_(ub)
         cc.copy_(d_c)
-        for d in (ca, cb, cc):
-            self.ntt.run(d.data_ptr(), False, COSET_SHIFT, st)
+        self.ntt.run_multi([(d.data_ptr(), d.data_ptr()) for d in (ca, cb, cc)], m, False, COSET_SHIFT, st)
         fr_quotient(h.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, m, st)
         self.ntt.run(h.data_ptr(), True, COSET_SHIFT, st)
         t_b2 = submit(self.g2, self.ext_b2, crs.d_s22, m + 2, 128)
