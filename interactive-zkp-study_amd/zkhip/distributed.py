@@ -320,6 +320,80 @@ class DistNtt:
         dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
         return recv
 
+    def _exchange_start(self, send):
+        """_exchange without waiting: -> (recv, work).  `work` is None when nothing is outstanding (one rank, or the host-staged
+        rehearsal of several ranks on one GPU); otherwise work.wait() orders the CURRENT stream behind the all-to-all, which RCCL
+        runs on a stream of its own -- kernels enqueued between the two calls run beside the exchange."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or (send.is_cuda and dist.get_backend(self.group) == "gloo"):
+            return self._exchange(send), None
+        recv = torch.empty_like(send)
+        return recv, dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group, async_op=True)
+
+    def forward_many(self, xs):
+        """forward() of several vectors in the block-cyclic layouts, the exchanges in flight together: vector j's all-to-all runs
+        under vector j+1's first local transform, and every second local transform starts when ITS exchange has landed (a
+        prover's A, B, C: three exchanges, two of them hidden).  Same results as forward() one by one."""
+        R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
+        fused = getattr(self.local, "fused", False)
+        pending = []
+        for x in xs:
+            if fused:
+                import torch
+                from ._lib import NTT_BLOCKED_TW, NTT_PLAIN
+                send = torch.empty((R, c, k, 4), dtype=x.dtype, device=x.device)
+                self.local.io(1, x, send, c, False, NTT_PLAIN, NTT_BLOCKED_TW, k.bit_length() - 1, self.rank * c)
+            else:
+                self.local.ntt_rows(x, 1, False)
+                self.local.twiddle(x, self.rank * c, False)
+                send = x.view(c, R, k, 4).permute(1, 0, 2, 3).contiguous()
+            pending.append((x, send) + self._exchange_start(send))
+        out = []
+        for x, send, recv, work in pending:
+            if work is not None:
+                work.wait()
+            if fused:
+                import torch
+                from ._lib import NTT_PLAIN, NTT_TRANSPOSED
+                rows = x.view(-1)[:k * n2 * 4].view(k, n2, 4) if x.numel() == k * n2 * 4 else torch.empty((k, n2, 4), dtype=x.dtype, device=x.device)
+                self.local.io(2, recv, rows, k, False, NTT_TRANSPOSED, NTT_PLAIN)
+            else:
+                rows = recv.view(n2, k, 4).permute(1, 0, 2).contiguous()
+                self.local.ntt_rows(rows, 2, False)
+            out.append(rows)
+        return out
+
+    def inverse_many(self, ys):
+        """inverse() of several vectors in the block-cyclic layouts with their exchanges in flight together (see forward_many)."""
+        R, n1, n2, c, k = self.world, self.n1, self.n2, self.c, self.k
+        fused = getattr(self.local, "fused", False)
+        pending = []
+        for y in ys:
+            if fused:
+                import torch
+                from ._lib import NTT_PLAIN, NTT_TRANSPOSED
+                send = torch.empty((R, c, k, 4), dtype=y.dtype, device=y.device)
+                self.local.io(2, y, send, k, True, NTT_PLAIN, NTT_TRANSPOSED)
+            else:
+                self.local.ntt_rows(y, 2, True)
+                send = y.view(k, R, c, 4).permute(1, 2, 0, 3).contiguous()
+            pending.append((y, send) + self._exchange_start(send))
+        out = []
+        for y, send, recv, work in pending:
+            if work is not None:
+                work.wait()
+            if fused:
+                from ._lib import NTT_BLOCKED_TW, NTT_PLAIN
+                cols = y.view(-1)[:c * n1 * 4].view(c, n1, 4)
+                self.local.io(1, recv, cols, c, True, NTT_BLOCKED_TW, NTT_PLAIN, k.bit_length() - 1, self.rank * c)
+            else:
+                cols = recv.permute(1, 0, 2, 3).contiguous().view(c, n1, 4)
+                self.local.twiddle(cols, self.rank * c, True)
+                self.local.ntt_rows(cols, 1, True)
+            out.append(cols)
+        return out
+
     # natural order across ranks ------------------------------------------------------------------
     # The block-cyclic layouts are what a prover's chain needs (transform -> pointwise -> inverse -> MSM never leaves them).  Where
     # the NATURAL order is wanted across ranks -- rank r holding the contiguous slice [r n/R, (r+1) n/R) -- it is one more

@@ -136,18 +136,17 @@ class DistScaleProver:
         r, s = r % R, s % R
         shape_ev, shape_co = (dn.k, dn.n2, 4), (dn.c, dn.n1, 4)
         # per-constraint values on the rank's rows, then coefficient form: 3 inverse transforms (one all-to-all each)
-        coef = []
+        # (the three exchanges of a group are in flight together: B's local transform runs under A's all-to-all, C's under B's --
+        # DistNtt.inverse_many / forward_many)
         for name, ev in zip("ABC", self.ev):
             rp, col, vals = crs.r1cs[name]
             fr_spmv(rp.data_ptr(), col.data_ptr(), vals.data_ptr(), d_w.data_ptr(), ev.data_ptr(), cn, st)
-            coef.append(dn.inverse(ev.view(shape_ev)).reshape(cn, 4))          # u_A, u_B, u_C: BC(n2), [j2 local][j1]
+        coef = [u.reshape(cn, 4) for u in dn.inverse_many([ev.view(shape_ev) for ev in self.ev])]   # u_A, u_B, u_C: BC(n2), [j2 local][j1]
         ua, ub, uc = coef
         # H = (A B - C) / Z on the coset: shift, 3 forward transforms, pointwise quotient, inverse transform, shift back
-        on_coset = []
         for u, buf in zip(coef, self.coset):
             FrVec.mul(buf.data_ptr(), u.data_ptr(), crs.cos_fwd.data_ptr(), cn, st)
-            on_coset.append(dn.forward(buf.view(shape_co)).reshape(cn, 4))
-        ca, cb, cc = on_coset
+        ca, cb, cc = (v.reshape(cn, 4) for v in dn.forward_many([buf.view(shape_co) for buf in self.coset]))
         fr_quotient(ca.data_ptr(), ca.data_ptr(), cb.data_ptr(), cc.data_ptr(), self.zinv, cn, st)
         h = dn.inverse(ca.view(shape_ev)).reshape(cn, 4)
         FrVec.mul(h.data_ptr(), h.data_ptr(), crs.cos_inv.data_ptr(), cn, st)

@@ -79,6 +79,13 @@ def _worker(rank, world, port, log_n, l1, ret):
         ok_i = ok_i and np.array_equal(inv_nat.numpy().view(np.uint64).reshape(-1, 4), full[rank * per:(rank + 1) * per])
         mixed = d.forward(torch.from_numpy(d.scatter_in(full).view(np.int64)), natural_out=True)       # block-cyclic in, natural out
         ok_n = ok_n and np.array_equal(mixed.numpy().view(np.uint64).reshape(-1, 4), want[rank * per:(rank + 1) * per])
+        # several vectors with their exchanges in flight together: the same results as one by one
+        fulls = [co.to_limbs([int.from_bytes(rng.bytes(32), "little") % o.R for _ in range(n)]) for _ in range(3)]
+        wants = [co.ntt_arr(f.copy(), omega, False) for f in fulls]
+        ys = d.forward_many([torch.from_numpy(d.scatter_in(f).view(np.int64)) for f in fulls])
+        ok_f = ok_f and all(np.array_equal(yy.numpy().view(np.uint64), d.scatter_out(w)) for yy, w in zip(ys, wants))
+        xs = d.inverse_many([yy.clone() for yy in ys])
+        ok_i = ok_i and all(np.array_equal(xx.numpy().view(np.uint64), d.scatter_in(f)) for xx, f in zip(xs, fulls))
         ret[rank] = (bool(ok_f and ok_n), bool(ok_i))
     finally:
         dist.destroy_process_group()
@@ -139,8 +146,8 @@ def _dry_worker(rank, world, port, ret):
         cn = dn.c * dn.n1
         assert cn == dn.k * dn.n2 == (1 << 20) // world
         shape_ev, shape_co = (dn.k, dn.n2, 4), (dn.c, dn.n1, 4)
-        coef = [dn.inverse(torch.zeros(shape_ev, dtype=torch.int64)).reshape(cn, 4) for _ in range(3)]
-        on_coset = [dn.forward(u.view(shape_co)).reshape(cn, 4) for u in coef]
+        coef = [u.reshape(cn, 4) for u in dn.inverse_many([torch.zeros(shape_ev, dtype=torch.int64) for _ in range(3)])]
+        on_coset = [v.reshape(cn, 4) for v in dn.forward_many([u.view(shape_co) for u in coef])]
         h = dn.inverse(on_coset[0].view(shape_ev)).reshape(cn, 4)
         assert tuple(h.shape) == (cn, 4) and sent == [cn * 32] * 7, sent
         mine = np.full(64, rank + 1, dtype=np.uint64)     # 16 + 16 + 32 limbs: the partials of proof_A, proof_C, proof_B
