@@ -197,10 +197,10 @@ class DevicePlonk:
         self._lin(q, [q], [zi], count - 1)
         return q
 
-    def _blinded(self, coef, blind):
-        """coef + blind(x) * (x^n - 1) in place (round1.py:92-108)."""
-        n, k = self.n, len(blind)
-        bl = _dev(_limbs(blind))
+    def _blinded(self, coef, bl):
+        """coef + blind(x) * (x^n - 1) in place (round1.py:92-108); bl: (k, 4) device tensor of the blinding scalars (uploaded once per
+        proof: a host-to-device copy of pageable memory in the middle of a round holds the host until the stream has drained)."""
+        n, k = self.n, bl.shape[0]
         self._lin(coef[:k], [coef[:k], bl], [1, R - 1], k)
         self._lin(coef[n:n + k], [coef[n:n + k], bl], [1, 1], k)
         return coef
@@ -337,8 +337,9 @@ class DevicePlonk:
 
         # round 1 (round1.py:55-108)
         B = self.buf
+        d_blind = _dev(_limbs(blind[:9]))                                             # all nine blinding scalars in one copy, before anything is queued
         wires = self._interpolate_many(cols, [B["w%d" % i] for i in range(3)])       # the three columns in one launch per pass
-        wires = [self._blinded(w, blind[2 * i:2 * i + 2]) for i, w in enumerate(wires)]
+        wires = [self._blinded(w, d_blind[2 * i:2 * i + 2]) for i, w in enumerate(wires)]
         tickets = [self._submit(w, n + 2) for w in wires]
         ea, eb, ec = self._coset_many(wires, self.work[:3])   # round 3's coset evaluations of the wires need no challenge: under the MSMs
         for name, t in zip(("a_comm", "b_comm", "c_comm"), tickets):
@@ -353,7 +354,8 @@ class DevicePlonk:
             beta, gamma = FR(challenges.get("beta", int(beta))), FR(challenges.get("gamma", int(gamma)))
         be, ga = int(beta), int(gamma)
         z_ev = self._accumulator(cols, be, ga)
-        z = self._blinded(self._interpolate(z_ev, B["z"]), blind[6:9])
+        z = self._interpolate(z_ev, B["z"])
+        z = self._blinded(z, d_blind[6:9])
         t_z = self._submit(z, n + 3)
         ez = self._coset(z, self.work[3])                    # likewise under the commitment of z
         ezw = self.work[4]
