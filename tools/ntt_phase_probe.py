@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Where a workgroup of the NTT pass kernels spends its life (measurement build only).
 
-    make -C interactive-zkp-study_amd/csrc   # the library
-    hipcc ... -DZK_NTT_STAMPS -c ntt.hip     # the variant (see profiles/r05_experiments.md), linked as tmp_variants/libzkhip_nttstamps.so
+    make -C tools nttstamps                  # the library with -DZK_NTT_STAMPS in ntt.hip -> tmp_variants/libzkhip_nttstamps.so
     python3 tools/ntt_phase_probe.py --lib tmp_variants/libzkhip_nttstamps.so [--log-n 22]
 
 Thread 0 of every workgroup stamps the 100 MHz wall clock at its phase boundaries (csrc/ntt.hip NTT_STAMP).  Printed per pass: the
