@@ -341,7 +341,18 @@ class ScaleProver:
         import torch
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else np.int64)).cuda()
         self.r1cs = {k: tuple(up(x) for x in v) for k, v in csr.items()}
-        self.abc = [torch.empty((self.m, 4), dtype=torch.int64, device="cuda") for _ in range(3)]
+        # A, B, C stacked into ONE CSR matrix of 3m rows: the three mat-vecs are one launch whose workgroups share the chip (three
+        # launches of 4096 latency-bound workgroups each ran one after the other at the start of every proof)
+        rp, col, vals, base = [np.zeros(1, dtype=np.uint32)], [], [], 0
+        for k in "ABC":
+            r_k, c_k, v_k = (np.ascontiguousarray(x) for x in csr[k])
+            rp.append(r_k[1:].astype(np.uint32) + np.uint32(base))
+            col.append(c_k)
+            vals.append(v_k)
+            base += int(r_k[-1])
+        self.r1cs_stacked = (up(np.concatenate(rp)), up(np.concatenate(col)), up(np.concatenate(vals)))
+        self.abc_all = torch.empty((3 * self.m, 4), dtype=torch.int64, device="cuda")
+        self.abc = [self.abc_all[i * self.m:(i + 1) * self.m] for i in range(3)]
 
     def prove_from_witness(self, d_w, r, s, stream=None):
         """Witness (W, 4) on the device -> proof: the scalar collapse A.w, B.w, C.w (zk_fr_spmv_dev; the reference's
@@ -353,9 +364,8 @@ class ScaleProver:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for name, out in zip("ABC", self.abc):
-            rp, col, vals = self.r1cs[name]
-            fr_spmv(rp.data_ptr(), col.data_ptr(), vals.data_ptr(), d_w.data_ptr(), out.data_ptr(), self.m, st)
+        rp, col, vals = self.r1cs_stacked
+        fr_spmv(rp.data_ptr(), col.data_ptr(), vals.data_ptr(), d_w.data_ptr(), self.abc_all.data_ptr(), 3 * self.m, st)
         if timed:
             e1.record()
         res = self.prove(self.abc[0], self.abc[1], self.abc[2], d_w, r, s, stream)
