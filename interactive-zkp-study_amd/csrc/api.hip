@@ -696,12 +696,20 @@ int zk_ntt_dev_multi(zk_ntt_plan *plan, unsigned jobs, const void *const *d_in, 
     return guarded([&] {
         if (!plan || (jobs && (!d_in || !d_out))) return invalid("zk_ntt_dev_multi: null pointer");
         if (jobs > NTT_MULTI_MAX) return invalid("zk_ntt_dev_multi: at most 4 transforms per call");
+        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev_multi")) return rc;
+        // byte ranges: an output is n elements, an input min(in_len, n); a job may transform in place (same address), nothing else may overlap
+        const size_t n = (size_t)1 << plan->impl->log_n(), out_bytes = n * 32, in_bytes = std::min(in_len, n) * 32;
+        auto overlap = [](const void *p, size_t pl, const void *q, size_t ql) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(p), b = reinterpret_cast<uintptr_t>(q);
+            return pl && ql && a < b + ql && b < a + pl;
+        };
         for (unsigned b = 0; b < jobs; b++) {
             if (!d_out[b] || (in_len && !d_in[b])) return invalid("zk_ntt_dev_multi: null buffer");
+            if (d_in[b] != d_out[b] && overlap(d_in[b], in_bytes, d_out[b], out_bytes)) return invalid("zk_ntt_dev_multi: a transform's input and output overlap without being the same buffer");
             for (unsigned c = 0; c < b; c++)
-                if (d_out[b] == d_out[c] || d_out[b] == d_in[c] || d_in[b] == d_out[c]) return invalid("zk_ntt_dev_multi: a buffer is written by one transform and used by another");
+                if (overlap(d_out[b], out_bytes, d_out[c], out_bytes) || overlap(d_out[b], out_bytes, d_in[c], in_bytes) || overlap(d_in[b], in_bytes, d_out[c], out_bytes))
+                    return invalid("zk_ntt_dev_multi: a buffer is written by one transform and used by another");
         }
-        if (int rc = check_plan_device(plan->impl->device(), "zk_ntt_dev_multi")) return rc;
         if (coset_shift && !fr_canonical_nonzero(coset_shift)) return invalid("zk_ntt_dev_multi: coset_shift must be a canonical non-zero element of F_r");
         plan->impl->run_multi(d_in, d_out, jobs, in_len, inverse != 0, coset_shift, (hipStream_t)stream);
         return ZK_OK;

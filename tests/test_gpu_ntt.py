@@ -346,6 +346,7 @@ def test_ntt_multi_at_2pow20_and_refusals():
     assert call([(a, c), (b, c)]) != 0             # c written twice
     assert call([(a, a)] * 5) != 0                 # more than four
     assert call([(a, a), (b, None)]) != 0          # null output
+    assert call([(a, a + 64), (b, b)]) != 0        # input and output of one job overlap without being the same buffer
     assert call([(a, a), (b, b)]) == 0             # in place is fine
     torch.cuda.synchronize()
     plan.close()
