@@ -137,7 +137,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--lib", default="", help="another build of libzkhip.so (same-session A/B runs)")
     ap.add_argument("--profile", action="store_true", help="cProfile one more prove() and print the host-side hot spots to stderr")
     ap.add_argument("--pause-after-proofs", type=float, default=0.0, help="seconds of GPU idleness between the timed proofs and the checks (marks the end of the last proof in a kernel trace)")
     args = ap.parse_args()
+    if args.lib:
+        from zkhip import _lib
+        _lib.LIB_PATH = args.lib
     print(json.dumps(run(args.log_n, args.reps, args.profile, args.pause_after_proofs)), flush=True)
